@@ -1,0 +1,493 @@
+// gmg_device.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the GMG-CG hot path.
+//
+// Everything here is HBM/L2-bandwidth work in fp64: no MFMA.  Design rules followed
+// (cdna_hip_programming.md G2/G11/G13, MI355X_MICROARCH.md):
+//   * CSR SpMV streams val/col with 16-byte-per-lane coalesced loads into an LDS "row window"
+//     (products of TILE consecutive nonzeros), then one lane per row sums its segment in CSR
+//     order -> bit-identical to the sequential CPU sum, no atomics, deterministic.
+//   * workgroup -> tile mapping is XCD-aware: blockIdx%8 labels the XCD (round-robin
+//     dispatch), each XCD owns a contiguous eighth of the tiles so the x-vector planes and
+//     the matrix slice it touches stay in that XCD's 4 MiB L2 from iteration to iteration.
+//   * reductions: per-workgroup partials written in a fixed layout; the *consumer* kernel's
+//     workgroups each re-reduce the (<= 1024) partials in a fixed order -- no fp64 atomics,
+//     no grid barrier, no host round trip; scalars (alpha, beta, residual) live on the device.
+//   * compiled with -ffp-contract=off: a*b+c rounds twice, exactly like the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmg {
+
+constexpr int kThreads = 256;      // 4 waves
+constexpr int kTileNnz = 4096;     // LDS row window, doubles (32 KiB) -> 4 workgroups / CU
+constexpr int kTileCap = 4092;     // max nnz of a regular tile (window start is rounded down to 4)
+constexpr int kPasses = kTileNnz / (kThreads * 4);
+constexpr int kMaxPartials = 1024; // upper bound of any grid that emits reduction partials
+
+// ---------------------------------------------------------------- reductions
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the sum
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// Sum over the workgroup, result broadcast to every thread.  Fixed order => deterministic.
+__device__ __forceinline__ double block_sum(double v, double *scratch /* >= 4 doubles of LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  return ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+
+__device__ __forceinline__ double block_max(double v, double *scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  return fmax(fmax(scratch[0], scratch[1]), fmax(scratch[2], scratch[3]));
+}
+
+// Every workgroup of a consumer kernel calls this on the producer's partials.
+__device__ __forceinline__ double reduce_partials(const double *p, int n, double *scratch) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kThreads) s += p[i];
+  return block_sum(s, scratch);
+}
+
+// ---------------------------------------------------------------- coarse-CG device state
+
+struct CGState {
+  double gh[2];       // g.h of the previous / current iteration (slot = iteration parity)
+  double res0;        // SolverControl::initial_value()
+  double res;         // SolverControl::last_value()
+  int it_k1;          // iterations completed, as seen by the SpMV kernel (written by it)
+  int it_k2;          // iterations completed, written by the update kernel
+  int done;           // 1 once converged / failed: every later kernel returns at once
+  int status;         // 0 success, 1 no convergence (step >= max or NaN)
+  int iters;          // SolverControl::last_step()
+  int pad;
+};
+
+// ---------------------------------------------------------------- CSR SpMV with LDS row window
+
+enum SpmvMode : int {
+  kStore = 0,   // y = acc
+  kResid = 1,   // y = b - acc                       (t.sadd(-1,1,defect); defect -= I^T u)
+  kAddTo = 2,   // y = b + acc                       (u += P u_c)
+  kJacobi = 3,  // y = x_i + (omega (b - acc)) invd  (one damped-Jacobi smoothing step)
+  kCheb = 4,    // w = c1 w + omega ((b - acc) invd) ; y = x_i + w   (Chebyshev recurrence step)
+};
+
+struct SpmvArgs {
+  const int32_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  const int32_t *tile_row;  // n_tiles + 1 row boundaries
+  int n_tiles;
+  int tiles_per_xcd;
+  const double *x;     // input vector (d_old when XFORM)
+  double *y;           // output vector (h when XFORM)
+  const double *init;  // optional: accumulation starts from init[i] (vmult_add / restrict_and_add)
+  const double *b;     // rhs / addend, by mode
+  const double *invd;  // 1/a_ii
+  double *w;           // Chebyshev direction vector
+  double omega, c1;
+  // --- XFORM (coarse CG): x_j := beta d_old[j] - g[j] on the fly, d_new and partial d.h out
+  const double *g;
+  double *dnew;
+  CGState *st;
+  const double *part_in;  // partials of |g|^2 from the update kernel
+  int n_part_in;
+  double *part_out;       // partials of d.h, one per workgroup
+  double tol;
+  int maxit;
+};
+
+// SolverCG between two iterations: res = |g| ; SolverControl::check ; beta = gh_new / gh_old.
+// Called by every workgroup of the kernel that opens an iteration; all of them derive the
+// same scalars from the same partials.  Returns false when the solve is over.
+__device__ __forceinline__ bool cg_open_iteration(CGState *st, const double *part_in, int n_part_in, double tol, int maxit,
+                                                  double *red, double *beta_out) {
+  if (st->done) return false;
+  const double gg = reduce_partials(part_in, n_part_in, red);
+  const double res = sqrt(gg);
+  const int it = st->it_k2;
+  const bool conv = res <= tol;
+  const bool fail = !conv && (it >= maxit || res != res);
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+  if (conv || fail) {
+    if (writer) {
+      st->done = 1;
+      st->status = conv ? 0 : 1;
+      st->res = res;
+      st->iters = it;
+      if (it == 0) st->res0 = res;
+    }
+    return false;
+  }
+  const double gh_new = res * res;
+  *beta_out = (it == 0) ? 0.0 : gh_new / st->gh[(it & 1) ^ 1];
+  if (writer) {
+    st->gh[it & 1] = gh_new;
+    st->it_k1 = it;
+    if (it == 0) st->res0 = res;
+  }
+  return true;
+}
+
+// CG = 0: plain operator application with epilogue MODE
+// CG = 1: single-GPU coarse CG, direction update fused in: x_j := beta d_old[j] - g[j]
+// CG = 2: distributed coarse CG: x is the already exchanged direction d; emits partial d.h
+template <int MODE, int CG>
+__global__ __launch_bounds__(kThreads) void spmv_tile_kernel(SpmvArgs a) {
+  __shared__ __attribute__((aligned(16))) double prod[kTileNnz + 8];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  constexpr bool XFORM = (CG == 1);
+
+  double beta = 0.0;
+  if constexpr (CG == 1) {
+    if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
+  }
+  if constexpr (CG == 2) {
+    if (a.st->done) return;
+  }
+
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
+  const int t_begin = xcd * a.tiles_per_xcd;
+  const int t_end = min(t_begin + a.tiles_per_xcd, a.n_tiles);
+  double dot_acc = 0.0;
+
+  for (int t = t_begin + lb; t < t_end; t += nb) {
+    const int r0 = a.tile_row[t], r1 = a.tile_row[t + 1];
+    const int k0 = a.rowptr[r0], k1 = a.rowptr[r1];
+    const int ka = k0 & ~3;
+    if (k1 - ka <= kTileNnz) {
+      // ---- phase A: stream 16 B/lane of col and 2 x 16 B/lane of val, gather x, products -> LDS
+      int4 c[kPasses];
+      double2 v0[kPasses], v1[kPasses];
+#pragma unroll
+      for (int p = 0; p < kPasses; ++p) {
+        const int base = ka + p * (kThreads * 4) + tid * 4;
+        if (base < k1) {
+          c[p] = *reinterpret_cast<const int4 *>(a.col + base);
+          v0[p] = *reinterpret_cast<const double2 *>(a.val + base);
+          v1[p] = *reinterpret_cast<const double2 *>(a.val + base + 2);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kPasses; ++p) {
+        const int base = ka + p * (kThreads * 4) + tid * 4;
+        if (base < k1) {
+          double x0, x1, x2, x3;
+          if constexpr (XFORM) {
+            x0 = beta * a.x[c[p].x] - a.g[c[p].x];
+            x1 = beta * a.x[c[p].y] - a.g[c[p].y];
+            x2 = beta * a.x[c[p].z] - a.g[c[p].z];
+            x3 = beta * a.x[c[p].w] - a.g[c[p].w];
+          } else {
+            x0 = a.x[c[p].x]; x1 = a.x[c[p].y]; x2 = a.x[c[p].z]; x3 = a.x[c[p].w];
+          }
+          double2 p01, p23;
+          p01.x = v0[p].x * x0; p01.y = v0[p].y * x1;
+          p23.x = v1[p].x * x2; p23.y = v1[p].y * x3;
+          double2 *dst = reinterpret_cast<double2 *>(prod + (base - ka));
+          dst[0] = p01;
+          dst[1] = p23;
+        }
+      }
+      __syncthreads();
+      // ---- phase B: one lane per row, sequential sum in CSR order
+      for (int r = r0 + tid; r < r1; r += kThreads) {
+        const int s = a.rowptr[r] - ka, e = a.rowptr[r + 1] - ka;
+        double acc = a.init ? a.init[r] : 0.0;
+        for (int k = s; k < e; ++k) acc += prod[k];
+        if constexpr (XFORM) {
+          const double dn = beta * a.x[r] - a.g[r];
+          a.dnew[r] = dn;
+          a.y[r] = acc;
+          dot_acc += dn * acc;
+        } else if constexpr (CG == 2) {
+          a.y[r] = acc;
+          dot_acc += a.x[r] * acc;
+        } else if constexpr (MODE == kStore) {
+          a.y[r] = acc;
+        } else if constexpr (MODE == kResid) {
+          a.y[r] = a.b[r] - acc;
+        } else if constexpr (MODE == kAddTo) {
+          a.y[r] = a.b[r] + acc;
+        } else if constexpr (MODE == kJacobi) {
+          a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
+        } else if constexpr (MODE == kCheb) {
+          const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
+          a.w[r] = wn;
+          a.y[r] = a.x[r] + wn;
+        }
+      }
+      __syncthreads();
+    } else {
+      // ---- long row (a single row wider than the window): strided partial sums, fixed order
+      double part = 0.0;
+      for (int k = k0 + tid; k < k1; k += kThreads) {
+        double xv;
+        if constexpr (XFORM) xv = beta * a.x[a.col[k]] - a.g[a.col[k]];
+        else xv = a.x[a.col[k]];
+        part += a.val[k] * xv;
+      }
+      const double tot = block_sum(part, red);
+      if (tid == 0) {
+        const int r = r0;
+        const double acc = (a.init ? a.init[r] : 0.0) + tot;
+        if constexpr (XFORM) {
+          const double dn = beta * a.x[r] - a.g[r];
+          a.dnew[r] = dn; a.y[r] = acc; dot_acc += dn * acc;
+        } else if constexpr (CG == 2) { a.y[r] = acc; dot_acc += a.x[r] * acc; }
+        else if constexpr (MODE == kStore) a.y[r] = acc;
+        else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;
+        else if constexpr (MODE == kAddTo) a.y[r] = a.b[r] + acc;
+        else if constexpr (MODE == kJacobi) a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
+        else if constexpr (MODE == kCheb) {
+          const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
+          a.w[r] = wn; a.y[r] = a.x[r] + wn;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (CG != 0) {
+    const double s = block_sum(dot_acc, red);
+    if (tid == 0) a.part_out[blockIdx.x] = s;
+  }
+}
+
+// Distributed coarse CG: opens the iteration and forms d = beta d - g on the owned range;
+// the ghost entries of d arrive by halo exchange before the SpMV (CG = 2).
+struct CGDirArgs {
+  double *d;
+  const double *g;
+  int64_t n;
+  CGState *st;
+  const double *part_in;
+  int n_part_in;
+  double tol;
+  int maxit;
+};
+__global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
+  __shared__ double red[4];
+  double beta = 0.0;
+  if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kThreads)
+    a.d[i] = beta * a.d[i] - a.g[i];
+}
+
+// ---------------------------------------------------------------- coarse CG: init + update
+
+struct CGInitArgs {
+  const double *b;
+  double *x, *g, *d0, *d1;
+  int64_t n;
+  CGState *st;
+  double *part_gg;
+};
+
+// x = 0 ; g = -b ; d buffers = 0 ; partials of |g|^2 ; reset state          (SolverCG entry, x == 0)
+__global__ __launch_bounds__(kThreads) void cg_init_kernel(CGInitArgs a) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kThreads) {
+    const double gi = -1.0 * a.b[i];
+    a.g[i] = gi;
+    a.x[i] = 0.0;
+    a.d0[i] = 0.0;
+    a.d1[i] = 0.0;
+    acc += gi * gi;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) a.part_gg[blockIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.st->gh[0] = a.st->gh[1] = 0.0;
+    a.st->res0 = a.st->res = 0.0;
+    a.st->it_k1 = a.st->it_k2 = 0;
+    a.st->done = 0; a.st->status = 0; a.st->iters = 0;
+  }
+}
+
+struct CGUpdateArgs {
+  double *x, *g;
+  const double *d, *h;
+  int64_t n;
+  CGState *st;
+  const double *part_dh;
+  int n_part_dh;
+  double *part_gg;
+};
+
+// alpha = gh / (d.h) ; x += alpha d ; g += alpha h ; partials of |g|^2
+__global__ __launch_bounds__(kThreads) void cg_update_kernel(CGUpdateArgs a) {
+  __shared__ double red[4];
+  if (a.st->done) return;
+  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
+  const int it = a.st->it_k1;
+  const double alpha = a.st->gh[it & 1] / dh;
+  double acc = 0.0;
+  const int64_t n2 = a.n >> 1;
+  const double2 *d2 = reinterpret_cast<const double2 *>(a.d);
+  const double2 *h2 = reinterpret_cast<const double2 *>(a.h);
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  double2 *g2 = reinterpret_cast<double2 *>(a.g);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+    const double2 dv = d2[i], hv = h2[i];
+    double2 xv = x2[i], gv = g2[i];
+    xv.x += alpha * dv.x; xv.y += alpha * dv.y;
+    gv.x += alpha * hv.x; gv.y += alpha * hv.y;
+    x2[i] = xv; g2[i] = gv;
+    acc += gv.x * gv.x;
+    acc += gv.y * gv.y;
+  }
+  if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.n - 1;
+    a.x[i] += alpha * a.d[i];
+    const double gi = a.g[i] + alpha * a.h[i];
+    a.g[i] = gi;
+    acc += gi * gi;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) a.part_gg[blockIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.st->it_k2 = it + 1;
+}
+
+// ---------------------------------------------------------------- BLAS-1 / gather / scatter
+
+__global__ __launch_bounds__(kThreads) void vec_equ_kernel(double *y, double a, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) y[i] = a * x[i];
+}
+__global__ __launch_bounds__(kThreads) void vec_add_kernel(double *y, double a, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) y[i] += a * x[i];
+}
+__global__ __launch_bounds__(kThreads) void vec_sadd_kernel(double *y, double s, double a, const double *x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+    y[i] = s * y[i] + a * x[i];
+}
+// y = (a x) * z   (Jacobi apply: (omega r) invd)
+__global__ __launch_bounds__(kThreads) void vec_scale_mul_kernel(double *y, double a, const double *x, const double *z, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+    y[i] = (a * x[i]) * z[i];
+}
+// Chebyshev start: w = (r invd) / theta ; y = w
+__global__ __launch_bounds__(kThreads) void cheb_first_kernel(double *y, double *w, const double *r, const double *invd, double theta, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const double wi = (r[i] * invd[i]) / theta;
+    w[i] = wi;
+    y[i] = wi;
+  }
+}
+// dst[idx_dst[k]] = src[idx_src[k]]   (copy_to_mg / copy_from_mg / halo pack)
+__global__ __launch_bounds__(kThreads) void gather_scatter_kernel(double *dst, const int32_t *idx_dst, const double *src,
+                                                                 const int32_t *idx_src, int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x; k < n; k += (int64_t)gridDim.x * kThreads) {
+    const int64_t id = idx_dst ? idx_dst[k] : k;
+    const int64_t is = idx_src ? idx_src[k] : k;
+    dst[id] = src[is];
+  }
+}
+
+// partial dot: out[blockIdx] ; finalised by reduce_final_kernel
+__global__ __launch_bounds__(kThreads) void dot_partial_kernel(const double *x, const double *y, int64_t n, double *part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) acc += x[i] * y[i];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// partials of (sum |x|, sum x^2, max |x|, count of nonzeros) -> part[4 * grid]
+__global__ __launch_bounds__(kThreads) void norms_partial_kernel(const double *x, int64_t n, double *part) {
+  __shared__ double red[4];
+  double s1 = 0.0, s2 = 0.0, mx = 0.0, nz = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const double v = x[i], av = fabs(v);
+    s1 += av; s2 += v * v; mx = fmax(mx, av); nz += (v != 0.0) ? 1.0 : 0.0;
+  }
+  const double r1 = block_sum(s1, red);
+  const double r2 = block_sum(s2, red);
+  const double r3 = block_max(mx, red);
+  const double r4 = block_sum(nz, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = r1;
+    part[gridDim.x + blockIdx.x] = r2;
+    part[2 * gridDim.x + blockIdx.x] = r3;
+    part[3 * gridDim.x + blockIdx.x] = r4;
+  }
+}
+// single workgroup: out[j] = reduce(part[j*n .. j*n+n)) ; op 0 = sum, 1 = max (per j via mask)
+__global__ __launch_bounds__(kThreads) void reduce_final_kernel(const double *part, int n, int n_out, unsigned max_mask, double *out) {
+  __shared__ double red[4];
+  for (int j = 0; j < n_out; ++j) {
+    const double *p = part + (int64_t)j * n;
+    double r;
+    if ((max_mask >> j) & 1u) {
+      double m = 0.0;
+      for (int i = threadIdx.x; i < n; i += kThreads) m = fmax(m, p[i]);
+      r = block_max(m, red);
+    } else {
+      r = reduce_partials(p, n, red);
+    }
+    if (threadIdx.x == 0) out[j] = r;
+  }
+}
+
+// ---------------------------------------------------------------- SSOR (level-scheduled SGS)
+// One workgroup sweeps the rows of its independent-set "stages" in order; rows inside a stage
+// have no mutual dependency, so the result equals the sequential Ifpack sweep in local row
+// order.  Used for levels >= 1, which are small (<= ~10^5 rows); launched as one workgroup
+// per connected chain of stages.
+struct SgsArgs {
+  const int32_t *rowptr;
+  const int32_t *col;
+  const double *val;
+  const double *invd;
+  const int32_t *stage_ptr;   // n_stages + 1
+  const int32_t *stage_rows;  // rows ordered by stage (forward order)
+  int n_stages;
+  double omega;
+  const double *r;
+  double *y;
+};
+
+// Cooperative multi-workgroup variant is not needed at these sizes: one launch per stage range.
+__global__ __launch_bounds__(kThreads) void sgs_stage_kernel(SgsArgs a, int stage) {
+  const int s = a.stage_ptr[stage], e = a.stage_ptr[stage + 1];
+  for (int q = s + blockIdx.x * kThreads + threadIdx.x; q < e; q += gridDim.x * kThreads) {
+    const int i = a.stage_rows[q];
+    double acc = 0.0;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) acc += a.val[k] * a.y[a.col[k]];
+    a.y[i] += a.omega * (a.r[i] - acc) * a.invd[i];
+  }
+}
+
+// All stages in one single-workgroup launch (small levels): __syncthreads between stages.
+__global__ __launch_bounds__(1024) void sgs_sweep_single_wg_kernel(SgsArgs a, int backward) {
+  for (int st = 0; st < a.n_stages; ++st) {
+    const int stage = backward ? a.n_stages - 1 - st : st;
+    const int s = a.stage_ptr[stage], e = a.stage_ptr[stage + 1];
+    for (int q = s + threadIdx.x; q < e; q += blockDim.x) {
+      const int i = a.stage_rows[q];
+      double acc = 0.0;
+      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) acc += a.val[k] * a.y[a.col[k]];
+      a.y[i] += a.omega * (a.r[i] - acc) * a.invd[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+}  // namespace gmg

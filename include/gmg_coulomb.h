@@ -1,0 +1,161 @@
+/* gmg_coulomb.h -- C-ABI of libgmgcoulomb.so: the MI355X (gfx950) implementation of the
+ * GMG-preconditioned CG hot path of the Step50 Poisson/Coulomb solver.
+ *
+ * The reference (vinayak-gholap1993/Geometric-Multigrid-preconditioners-for-long-range-
+ * Coulomb-interaction) has no FFI for this path: LaplaceProblem::solve()
+ * (src/step-50.cc:938-1017) wires deal.II class templates together inline.  The seams are
+ * deal.II's duck-typed concepts; every entry point below names the concept
+ * member / call site it stands in for.  A maintainer binds them with the 20-line adapter
+ * classes shown in INTEGRATION.md and passes those to SolverCG::solve at :991.
+ *
+ * Conventions
+ *   - every function returns int: GMG_OK or a GMG_ERR_* code; no C++ exception crosses the ABI;
+ *     gmg_last_error() gives the text of the last failure on that context.
+ *   - matrices are handed over as host CSR arrays (int64 rowptr, int32 col, fp64 val) and
+ *     copied; they are immutable until replaced (the reference rebuilds them once per
+ *     adaptive cycle, src/step-50.cc:1545-1548).  Explicitly stored zeros are kept.
+ *   - vectors are device pointers (fp64) obtained from gmg_vec_alloc(); the caller owns them.
+ *   - one host thread per context, one HIP stream per context; calls on one context are
+ *     serialised by the caller (the reference runs single-threaded ranks, src/main.cc:8).
+ *   - functions that return a scalar to the host (dot, norms, solves) block until it is
+ *     available; everything else is asynchronous on the context's stream.
+ *   - distributed runs: one process per GPU, rows of every operator are the locally owned
+ *     range, columns index [owned | ghost] entries; see gmg_set_halo_plan().
+ */
+#ifndef GMG_COULOMB_H
+#define GMG_COULOMB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMG_OK 0
+#define GMG_ERR_INVALID 1        /* bad argument / wrong call order                         */
+#define GMG_ERR_OUTER_NOCONV 2   /* outer CG hit max_it: deal.II SolverControl::NoConvergence, :942 */
+#define GMG_ERR_COARSE_NOCONV 3  /* coarse CG hit 1000 its: NoConvergence from :962-967     */
+#define GMG_ERR_HIP 4            /* a HIP runtime call failed                               */
+#define GMG_ERR_COMM 5           /* RCCL failure / communicator not initialised             */
+#define GMG_ERR_UNSUPPORTED 6
+
+/* `which` argument of gmg_spmv & co.: a level number >= 0, or the active-mesh matrix */
+#define GMG_SYSTEM (-1)
+
+/* smoother kinds: src/step-50.cc:969 (Jacobi, commented), :970 (SSOR); Chebyshev is this
+ * build's addition for BASELINE config 3 (not in the reference, parity unpinned)        */
+#define GMG_SMOOTHER_JACOBI 0
+#define GMG_SMOOTHER_SSOR 1
+#define GMG_SMOOTHER_CHEBYSHEV 2
+
+/* preconditioner of gmg_cg_solve: prm "Preconditioner = GMG | Jacobi", src/step-50.cc:954, :996 */
+#define GMG_PRECOND_GMG 0
+#define GMG_PRECOND_JACOBI 1
+#define GMG_PRECOND_IDENTITY 2
+
+typedef struct gmg_context gmg_context;
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+/* Replaces the construction of the object graph in solve(), src/step-50.cc:954-989.
+ * n_levels = triangulation.n_global_levels() (:709).                                      */
+int gmg_create(gmg_context **ctx, int device_id, int n_levels);
+int gmg_destroy(gmg_context *ctx);
+const char *gmg_last_error(const gmg_context *ctx);
+int gmg_synchronize(gmg_context *ctx);
+
+/* ---- operators ---------------------------------------------------------------------- */
+/* system_matrix (include/step_50.h:156; filled src/step-50.cc:793-795, 831).              */
+int gmg_set_system_matrix(gmg_context *ctx, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                          const int32_t *col, const double *val);
+/* mg_matrices[level] (include/step_50.h:168; filled src/step-50.cc:869-889, 930).         */
+int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                         const int32_t *col, const double *val);
+/* mg_interface_matrices[level] (include/step_50.h:169; src/step-50.cc:892-925, 931); used as
+ * both edge_out and edge_in, mg.set_edge_matrices(down, up) at :986.  Zeros may be pruned. */
+int gmg_set_edge_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                        const int32_t *col, const double *val);
+/* MGTransferPrebuilt::build_matrices product (src/step-50.cc:957-958): P maps `level` to
+ * `level+1`, n_fine x n_coarse; the library builds the transpose for restrict_and_add.     */
+int gmg_set_prolongation(gmg_context *ctx, int level, int64_t n_fine, int64_t n_coarse, const int64_t *rowptr,
+                         const int32_t *col, const double *val);
+/* MGTransferPrebuilt copy_indices[level] (used by PreconditionMG::vmult, :988-989).        */
+int gmg_set_copy_indices(gmg_context *ctx, int level, int64_t n, const int32_t *global_idx, const int32_t *level_idx);
+/* mg_smoother.initialize(mg_matrices, AdditionalData(omega)); set_steps(steps), :971-973.
+ * cheb_*: Chebyshev degree, eigenvalue ratio and lambda_max of D^-1 A (0 = Gershgorin).    */
+int gmg_set_smoother(gmg_context *ctx, int kind, double omega, int steps, int cheb_degree, double cheb_ratio,
+                     double cheb_lmax);
+/* SolverControl coarse_solver_control(1000, 1e-10, false, false), :962.                    */
+int gmg_set_coarse(gmg_context *ctx, double abs_tol, int max_it);
+
+/* ---- vector_t (LA::MPI::Vector, include/step_50.h:154) ----------------------------- */
+int gmg_vec_alloc(gmg_context *ctx, int64_t n, double **dptr);
+int gmg_vec_free(gmg_context *ctx, double *dptr);
+int gmg_vec_upload(gmg_context *ctx, double *dst_dev, const double *src_host, int64_t n);
+int gmg_vec_download(gmg_context *ctx, double *dst_host, const double *src_dev, int64_t n);
+int gmg_vec_set_zero(gmg_context *ctx, double *x, int64_t n);                               /* v = 0        */
+int gmg_vec_equ(gmg_context *ctx, double *y, double a, const double *x, int64_t n);         /* y.equ(a,x)   */
+int gmg_vec_add(gmg_context *ctx, double *y, double a, const double *x, int64_t n);         /* y.add(a,x)   */
+int gmg_vec_sadd(gmg_context *ctx, double *y, double s, double a, const double *x, int64_t n); /* y.sadd(s,a,x) */
+int gmg_vec_dot(gmg_context *ctx, const double *x, const double *y, int64_t n, double *out); /* x*y (all-reduced) */
+int gmg_vec_norms(gmg_context *ctx, const double *x, int64_t n, double *l1, double *l2, double *linf); /* :946-948, :1012-1014 */
+int gmg_vec_all_zero(gmg_context *ctx, const double *x, int64_t n, int *out);               /* x.all_zero() */
+
+/* ---- the concepts SolverCG / Multigrid consume ------------------------------------- */
+/* matrix.vmult(dst, src): SolverCG matrix concept (:991 system_matrix, :965 coarse_matrix);
+ * also mg::Matrix::vmult(level, ...) (:975).  Includes the ghost import.                  */
+int gmg_spmv(gmg_context *ctx, int which, double *dst, const double *src);
+/* PreconditionMG::vmult(dst, src): copy_to_mg, one V-cycle (Multigrid::cycle), copy_from_mg
+ * (:980-989).  Fails with GMG_ERR_COARSE_NOCONV like the reference's exception.           */
+int gmg_precondition(gmg_context *ctx, double *dst, const double *src);
+/* PreconditionJacobi(omega).vmult on the system matrix (:999-1004, omega = 0.6).           */
+int gmg_precondition_jacobi(gmg_context *ctx, double omega, double *dst, const double *src);
+/* MGCoarseGridIterativeSolver::operator()(0, dst, src) (:965-967): unpreconditioned CG from
+ * zero on mg_matrices[0], device resident; returns iteration count and final residual.    */
+int gmg_coarse_solve(gmg_context *ctx, double *dst, const double *src, int *iterations, double *residual);
+/* MGSmootherBase::apply (from_zero != 0) / ::smooth (from_zero == 0) on one level (:983-984). */
+int gmg_smoother_step(gmg_context *ctx, int level, double *u, const double *rhs, int from_zero);
+/* MGTransferBase::prolongate(level+1, dst, src) / restrict_and_add(level+1, dst, src).     */
+int gmg_prolongate(gmg_context *ctx, int level, double *dst_fine, const double *src_coarse);
+int gmg_restrict_and_add(gmg_context *ctx, int level, double *dst_coarse, const double *src_fine);
+
+/* ---- optional: the whole outer solve on the device side of the ABI ------------------ */
+/* solver.solve(system_matrix, solution, system_rhs, preconditioner) (:991-992 / :1003-1004)
+ * with tol = rel_tol * |b|_2 (:942).  The north-star layout keeps this loop in the host C++
+ * (csrc/host/laplace_problem.cc) on top of the calls above; this entry runs the same
+ * operation order inside the library to avoid the per-call launch latency.               */
+int gmg_cg_solve(gmg_context *ctx, double *x, const double *b, double rel_tol, int max_it, int precond,
+                 int *iterations, double *starting_value, double *convergence_value);
+
+/* ---- distributed (one process per GPU, RCCL over xGMI) ------------------------------ */
+#define GMG_UNIQUE_ID_BYTES 128
+int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broadcast by the host */
+int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
+/* Epetra_Import plan of one operator: for each neighbour the owned local rows to send and
+ * the number of ghost values received; ghosts are stored behind the owned entries in
+ * neighbour order.  `which` as in gmg_spmv.                                              */
+int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_t *neighbor_rank,
+                      const int32_t *send_count, const int32_t *send_idx, const int32_t *recv_count);
+
+/* ---- measurement -------------------------------------------------------------------- */
+typedef struct gmg_stats {
+  int64_t coarse_solves;        /* calls of the coarse solver since the last reset           */
+  int64_t coarse_iterations;    /* inner CG iterations summed over those calls               */
+  int64_t vcycles;
+  int64_t spmv0_samples;        /* level-0 SpMV launches bracketed by HIP events             */
+  double spmv0_ms_total;        /* summed event time of those launches                       */
+  int64_t spmv0_rows, spmv0_nnz; /* shape of the level-0 operator (for algorithmic bytes)    */
+  int64_t cgupd_samples;
+  double cgupd_ms_total;
+} gmg_stats;
+int gmg_stats_reset(gmg_context *ctx);
+int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
+/* bracket every `sample_every`-th level-0 SpMV launch with HIP events (0 = off).           */
+int gmg_set_profiling(gmg_context *ctx, int sample_every);
+/* tuning knobs (0 keeps the default): iterations enqueued between host convergence checks,
+ * use of hipGraph replay for the coarse-CG iteration chunk.                               */
+int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMG_COULOMB_H */
