@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- DoF/s per CG iteration of the GMG-preconditioned CG solve on MI355X.
+
+A "step" is one pass of the hot path (LaplaceProblem::solve, src/step-50.cc:938-1017: outer CG
+to 1e-8 |b| with one V-cycle per iteration) on the operators of one adaptive cycle, from the
+cycle's initial guess, with every operator and vector already resident in HBM.  value =
+(active DoFs x outer CG iterations) / time per step, summed over what all ranks solve.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2 [--workload atoms64000|atoms8000|atoms1000|atoms8|stress201]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "geometric-multigrid-preconditioners-for-long-range-coulomb-interaction_amd"
+
+# BASELINE.json configs 2-5: NaCl cells per side, box length
+WORKLOADS = {
+    "atoms8": dict(nacl=1, box=1.0, label="3D gaussian-charges, atom_n1_8 (8 atoms), 45^3 level 0"),
+    "atoms1000": dict(nacl=5, box=5.0, label="3D atom_n5_1000 (1000 atoms), 61^3 level 0"),
+    "atoms8000": dict(nacl=10, box=10.0, label="3D atom_n10_8000 (8000 atoms), 81^3 level 0"),
+    "atoms64000": dict(nacl=20, box=20.0, label="3D atom_n20_64000 (64k atoms), 121^3 level 0"),
+    "stress201": dict(nacl=40, box=40.0, label="3D NaCl 512k atoms (same generator), 201^3 level 0"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def spmv_bytes(n, nnz):
+    return 12 * nnz + 4 * (n + 1) + 16 * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="atoms64000", choices=sorted(WORKLOADS))
+    ap.add_argument("--smoother", default="Jacobi", choices=["Jacobi", "SSOR", "Chebyshev"])
+    ap.add_argument("--cycles", type=int, default=1, help="adaptive cycles to build; the last one is timed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    pkg = importlib.import_module(PKG)
+    S = pkg.step50
+    w = WORKLOADS[args.workload]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    os.environ["STEP50_DEVICE"] = str(local_rank)
+    p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
+                             bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
+                             quad_rhs=1, global_refinement=0, smoother=args.smoother))
+    p.set_nacl_atoms(w["nacl"])
+    t_setup = time.time()
+    rep = None
+    for cycle in range(args.cycles):
+        rep = p.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed)
+    t_setup = time.time() - t_setup
+    ctx = pkg.capi.Context.view(p.gmg_context())  # non-owning view of the problem's gmg_context (stats)
+
+    for _ in range(args.warmup):
+        p.solve_again()
+    ctx.set_profiling(args.profile_every)
+    ctx.stats_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rep_t = p.solve_again()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_profiling(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    dofs, its = rep["dofs"], rep_t["cg_iterations"]
+    value = dofs * its * world / (dt / args.steps)
+
+    n0, nnz0 = st.spmv0_rows, st.spmv0_nnz
+    roof = None
+    if st.spmv0_samples > 0:
+        t_k = st.spmv0_ms_total / st.spmv0_samples * 1e-3
+        # the level-0 kernel is SpMV + fused direction update: SpMV bytes + 16 N (reads g, writes d)
+        alg = spmv_bytes(n0, nnz0) + 16 * n0
+        ach = alg / t_k / 1e9
+        roof = {"bound": "hbm", "kernel": "spmv_tile_kernel<kStore,1> (level-0 SpMV + CG direction update)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2),
+                "launches_sampled": int(st.spmv0_samples)}
+        if st.cgupd_samples > 0:
+            t_u = st.cgupd_ms_total / st.cgupd_samples * 1e-3
+            roof["cg_update_kernel"] = {"avg_launch_us": round(t_u * 1e6, 2), "bytes_per_launch": 48 * n0,
+                                        "achieved": round(48 * n0 / t_u / 1e9, 1)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(p, rep, args.smoother)
+
+    if rank == 0:
+        out = {
+            "metric": "DoF/s per CG-iter (GMG-precond Poisson, 3D)", "value": value, "unit": "DoF*it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["label"], "cycle": args.cycles - 1, "smoother": args.smoother,
+                       "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
+                       "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
+                       "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),
+                       "parallelism": f"{world} rank(s), one per GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    p.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(p, rep, smoother):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on the same
+    operators: one full solve of the timed cycle when it fits ~30 s, else a bounded number of
+    level-0 CG iterations scaled up."""
+    from oracle import gmg_oracle as go
+
+    threads = min(go.max_threads(), os.cpu_count() or 1)
+    go.set_threads(threads)
+    h = p.hierarchy()
+    kind = {"Jacobi": go.JACOBI, "SSOR": go.SSOR, "Chebyshev": go.CHEBYSHEV}[smoother]
+    n0 = h.level_matrices[0].n_rows
+    budget_its = max(8, int(25.0 / (2.5e-8 * h.level_matrices[0].nnz / max(1, threads) * 4 + 1e-9)))
+    full = rep["coarse_iterations"] <= budget_its
+    t0 = time.perf_counter()
+    if full:
+        mg = go.OracleMG(h, smoother=kind)
+        r = mg.solve(h.system_rhs, x0=p.vector("initial_guess"))
+        dt = time.perf_counter() - t0
+        value = rep["dofs"] * r["iterations"] / dt
+        sample = f"one full solve of the timed cycle: {r['iterations']} outer / {r['coarse_iterations']} coarse CG iterations, {dt:.2f} s"
+    else:
+        mg = go.OracleMG(h, smoother=kind, coarse_maxit=budget_its)
+        mg.coarse_solve(h.system_rhs if len(h.level_matrices) == 1 else h.system_rhs[:n0] * 0 + 1.0)
+        dt = time.perf_counter() - t0
+        per_it = dt / budget_its
+        est = per_it * rep["coarse_iterations"]
+        value = rep["dofs"] * rep["cg_iterations"] / est
+        sample = f"{budget_its} level-0 CG iterations ({dt:.2f} s), scaled to the {rep['coarse_iterations']} of one step"
+    go.set_threads(1)
+    return {"value": value, "unit": "DoF*it/s", "cores": threads, "kind": "port", "sample": sample}
+
+
+if __name__ == "__main__":
+    main()

@@ -7,4 +7,4 @@ The directory name contains hyphens; import it with
 
     importlib.import_module("geometric-multigrid-preconditioners-for-long-range-coulomb-interaction_amd")
 """
-from . import build, capi  # noqa: F401
+from . import build, capi, step50  # noqa: F401

@@ -106,10 +106,20 @@ class Context:
         self.n_levels = n_levels
         self.n_system = 0
 
+    @classmethod
+    def view(cls, handle):
+        """Non-owning view of a gmg_context* created elsewhere (the host-side C++)."""
+        self = cls.__new__(cls)
+        self.L, self.h, self.owned = load(), handle, False
+        self.n_levels = self.n_system = 0
+        return self
+
+    owned = True
+
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             self.L.gmg_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -1,0 +1,1251 @@
+// laplace_problem.cc -- see laplace_problem.h.  Reference line numbers are those of
+// /root/reference/src/step-50.cc unless another file is named.
+#include "laplace_problem.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+namespace step50 {
+
+// ======================================================================== CSR helpers
+
+void CSRMatrix::add(int32_t r, int32_t c, double v) {
+  const int32_t *b = col.data() + rowptr[(size_t)r], *e = col.data() + rowptr[(size_t)r + 1];
+  const int32_t *p = std::lower_bound(b, e, c);
+  if (p == e || *p != c) throw std::logic_error("CSRMatrix::add: entry outside the sparsity pattern");
+  val[(size_t)(p - col.data())] += v;
+}
+double CSRMatrix::l1_norm() const {
+  std::vector<double> s((size_t)n_cols, 0.0);
+  for (int64_t k = 0; k < nnz(); ++k) s[(size_t)col[(size_t)k]] += std::fabs(val[(size_t)k]);
+  double m = 0;
+  for (double v : s) m = std::max(m, v);
+  return m;
+}
+double CSRMatrix::linfty_norm() const {
+  double m = 0;
+  for (int64_t i = 0; i < n_rows; ++i) {
+    double s = 0;
+    for (int64_t k = rowptr[(size_t)i]; k < rowptr[(size_t)i + 1]; ++k) s += std::fabs(val[(size_t)k]);
+    m = std::max(m, s);
+  }
+  return m;
+}
+double CSRMatrix::frobenius_norm() const {
+  double s = 0;
+  for (double v : val) s += v * v;
+  return std::sqrt(s);
+}
+
+namespace {
+
+// Pattern from per-cell coupling lists: all pairs inside a list are stored entries (value 0).
+CSRMatrix pattern_from_cells(int64_t n, const std::vector<int64_t> &cptr, const std::vector<int32_t> &citems) {
+  const int64_t n_cells = (int64_t)cptr.size() - 1;
+  std::vector<int64_t> dptr((size_t)n + 1, 0);
+  for (int32_t d : citems) dptr[(size_t)d + 1]++;
+  for (int64_t i = 0; i < n; ++i) dptr[(size_t)i + 1] += dptr[(size_t)i];
+  std::vector<int32_t> dcells((size_t)dptr[(size_t)n]);
+  {
+    std::vector<int64_t> pos(dptr.begin(), dptr.end() - 1);
+    for (int64_t c = 0; c < n_cells; ++c)
+      for (int64_t k = cptr[(size_t)c]; k < cptr[(size_t)c + 1]; ++k) dcells[(size_t)pos[(size_t)citems[(size_t)k]]++] = (int32_t)c;
+  }
+  CSRMatrix A;
+  A.n_rows = A.n_cols = n;
+  A.rowptr.assign((size_t)n + 1, 0);
+  std::vector<std::vector<int32_t>> rows;  // filled in parallel chunks to bound memory
+  const int64_t chunk = 1 << 16;
+  std::vector<int32_t> all;
+  std::vector<int64_t> counts((size_t)n, 0);
+  // pass 1: counts
+#pragma omp parallel
+  {
+    std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; ++i) {
+      tmp.clear();
+      for (int64_t q = dptr[(size_t)i]; q < dptr[(size_t)i + 1]; ++q) {
+        const int32_t c = dcells[(size_t)q];
+        tmp.insert(tmp.end(), citems.begin() + cptr[(size_t)c], citems.begin() + cptr[(size_t)c + 1]);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      counts[(size_t)i] = std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+    }
+  }
+  (void)chunk;
+  for (int64_t i = 0; i < n; ++i) A.rowptr[(size_t)i + 1] = A.rowptr[(size_t)i] + counts[(size_t)i];
+  A.col.resize((size_t)A.rowptr[(size_t)n]);
+  A.val.assign((size_t)A.rowptr[(size_t)n], 0.0);
+#pragma omp parallel
+  {
+    std::vector<int32_t> tmp;
+#pragma omp for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; ++i) {
+      tmp.clear();
+      for (int64_t q = dptr[(size_t)i]; q < dptr[(size_t)i + 1]; ++q) {
+        const int32_t c = dcells[(size_t)q];
+        tmp.insert(tmp.end(), citems.begin() + cptr[(size_t)c], citems.begin() + cptr[(size_t)c + 1]);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      const auto e = std::unique(tmp.begin(), tmp.end());
+      std::copy(tmp.begin(), e, A.col.begin() + A.rowptr[(size_t)i]);
+    }
+  }
+  return A;
+}
+
+CSRMatrix csr_from_triplets(int64_t n_rows, int64_t n_cols, std::vector<std::array<int64_t, 2>> &rc, std::vector<double> &v,
+                            bool sum_duplicates) {
+  std::vector<size_t> order(rc.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rc[a] < rc[b]; });
+  CSRMatrix A;
+  A.n_rows = n_rows; A.n_cols = n_cols;
+  A.rowptr.assign((size_t)n_rows + 1, 0);
+  for (size_t q = 0; q < order.size(); ++q) {
+    const size_t i = order[q];
+    if (q > 0 && rc[i] == rc[order[q - 1]]) {
+      if (sum_duplicates) A.val.back() += v[i];
+      continue;  // "set" semantics: first writer wins, later ones are identical
+    }
+    A.col.push_back((int32_t)rc[i][1]);
+    A.val.push_back(v[i]);
+    A.rowptr[(size_t)rc[i][0] + 1]++;
+  }
+  for (int64_t i = 0; i < n_rows; ++i) A.rowptr[(size_t)i + 1] += A.rowptr[(size_t)i];
+  return A;
+}
+
+// Gauss-Legendre on [0,1]
+void gauss01(int n, std::vector<double> &x, std::vector<double> &w) {
+  x.resize((size_t)n); w.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    double z = std::cos(M_PI * (i + 0.75) / (n + 0.5)), pp = 0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = 1, p2 = 0;
+      for (int j = 1; j <= n; ++j) { const double p3 = p2; p2 = p1; p1 = ((2.0 * j - 1) * z * p2 - (j - 1.0) * p3) / j; }
+      pp = n * (z * p1 - p2) / (z * z - 1);
+      const double dz = p1 / pp;
+      z -= dz;
+      if (std::fabs(dz) < 1e-16) break;
+    }
+    x[(size_t)(n - 1 - i)] = 0.5 * (z + 1);
+    w[(size_t)(n - 1 - i)] = 1.0 / ((1 - z * z) * pp * pp);
+  }
+}
+
+template <int dim>
+struct Quadrature {  // QGauss<dim>(n), tensor product with x fastest
+  std::vector<std::array<double, 3>> p;
+  std::vector<double> w;
+  std::vector<std::array<double, 1 << dim>> shape;                       // [q][i]
+  std::vector<std::array<std::array<double, 3>, 1 << dim>> grad;        // [q][i][d], unit cell
+  explicit Quadrature(int n) {
+    std::vector<double> x1, w1;
+    gauss01(n, x1, w1);
+    const int nz = dim == 3 ? n : 1;
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+          p.push_back({x1[(size_t)i], x1[(size_t)j], dim == 3 ? x1[(size_t)k] : 0.0});
+          w.push_back(w1[(size_t)i] * w1[(size_t)j] * (dim == 3 ? w1[(size_t)k] : 1.0));
+        }
+    shape.resize(p.size()); grad.resize(p.size());
+    for (size_t q = 0; q < p.size(); ++q)
+      for (int a = 0; a < (1 << dim); ++a) {
+        double f[3], df[3];
+        for (int d = 0; d < dim; ++d) {
+          const int b = (a >> d) & 1;
+          f[d] = b ? p[q][(size_t)d] : 1.0 - p[q][(size_t)d];
+          df[d] = b ? 1.0 : -1.0;
+        }
+        double v = 1;
+        for (int d = 0; d < dim; ++d) v *= f[d];
+        shape[q][(size_t)a] = v;
+        for (int e = 0; e < 3; ++e) {
+          double g = 0;
+          if (e < dim) { g = 1; for (int d = 0; d < dim; ++d) g *= (d == e) ? df[d] : f[d]; }
+          grad[q][(size_t)a][(size_t)e] = g;
+        }
+      }
+  }
+};
+
+std::string fmt(const char *f, double v) {
+  char buf[64];
+  std::snprintf(buf, sizeof buf, f, v);
+  return buf;
+}
+
+}  // namespace
+
+// ======================================================================== parameters
+
+void ParameterReader::declare_parameters() {
+  values = {{"Number of global refinement", "2"}, {"Domain limit left", "-1"}, {"Domain limit right", "1"},
+            {"Mesh size", "0.25"}, {"Vacuum repetitions", "1"}, {"Problem", "Step16"}, {"Dimension", "2"},
+            {"Boundary conditions selection", "Inhomogeneous"}, {"Number of Adaptive Refinement", "2"},
+            {"smoothing length", "0.5"}, {"Nonzero Density radius parameter around each charge", "3"},
+            {"Output and calculation of Analytical solution", "false"}, {"Output of RHS field", "false"},
+            {"Output of support of each atom", "false"}, {"Flag for RHS evaluation optimization", "false"},
+            {"Quadrature points for RHS function", "1"}, {"Output time summary table", "true"},
+            {"Polynomial degree", "1"}, {"Preconditioner", "GMG"}, {"Lammps input file", "atom_8.data"},
+            // additions of this build (the reference selects the smoother by editing :969-970)
+            {"Smoother", "SSOR"}, {"Smoother damping", "0.5"}, {"Smoother steps", "2"}, {"Chebyshev degree", "2"},
+            {"Device resident outer CG", "false"}};
+}
+void ParameterReader::parse_input_from_string(const std::string &text) {
+  std::istringstream in(text);
+  std::string line;
+  while (std::getline(in, line)) {
+    const size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    const size_t s = line.find("set ");
+    if (s == std::string::npos) continue;
+    const size_t eq = line.find('=', s);
+    if (eq == std::string::npos) continue;
+    auto trim = [](std::string t) {
+      const size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r");
+      return a == std::string::npos ? std::string() : t.substr(a, b - a + 1);
+    };
+    const std::string key = trim(line.substr(s + 4, eq - s - 4));
+    if (!values.count(key)) throw std::runtime_error("ParameterHandler: undeclared entry <" + key + ">");
+    values[key] = trim(line.substr(eq + 1));
+  }
+}
+void ParameterReader::read_parameters(const std::string &file) {
+  std::ifstream in(file);
+  if (!in) throw std::runtime_error("cannot open parameter file " + file);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  parse_input_from_string(ss.str());
+}
+std::string ParameterReader::get(const std::string &k) const { return values.at(k); }
+double ParameterReader::get_double(const std::string &k) const { return std::stod(values.at(k)); }
+long ParameterReader::get_integer(const std::string &k) const { return std::stol(values.at(k)); }
+bool ParameterReader::get_bool(const std::string &k) const { return values.at(k) == "true"; }
+
+Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
+  Parameters p;
+  p.number_of_global_refinement = (unsigned)prm.get_integer("Number of global refinement");
+  p.domain_size_left = prm.get_double("Domain limit left");
+  p.domain_size_right = prm.get_double("Domain limit right");
+  p.mesh_size_h = prm.get_double("Mesh size");
+  p.repetitions_for_vacuum = (unsigned)prm.get_integer("Vacuum repetitions");
+  p.number_of_adaptive_refinement_cycles = (unsigned)prm.get_integer("Number of Adaptive Refinement");
+  p.r_c = prm.get_double("smoothing length");
+  p.nonzero_density_radius_parameter = prm.get_double("Nonzero Density radius parameter around each charge");
+  p.flag_analytical_solution = prm.get_bool("Output and calculation of Analytical solution");
+  p.flag_rhs_field = prm.get_bool("Output of RHS field");
+  p.flag_atoms_support = prm.get_bool("Output of support of each atom");
+  p.flag_rhs_assembly = prm.get_bool("Flag for RHS evaluation optimization");
+  p.quadrature_degree_rhs = (unsigned)prm.get_integer("Quadrature points for RHS function");
+  p.flag_output_time = prm.get_bool("Output time summary table");
+  p.degree = (unsigned)prm.get_integer("Polynomial degree");
+  p.PreconditionerType = prm.get("Preconditioner");
+  p.Problemtype = prm.get("Problem");
+  p.dim = (int)prm.get_integer("Dimension");
+  p.Boundary_conditions = prm.get("Boundary conditions selection");
+  p.LammpsInputFile = prm.get("Lammps input file");
+  p.smoother = prm.get("Smoother");
+  p.smoother_omega = prm.get_double("Smoother damping");
+  p.smoother_steps = (int)prm.get_integer("Smoother steps");
+  p.chebyshev_degree = (int)prm.get_integer("Chebyshev degree");
+  p.device_resident_outer_cg = prm.get_bool("Device resident outer CG");
+  return p;
+}
+
+std::vector<double> nacl_lattice(int n, std::vector<double> &q) {
+  // atom/atom_n{1,3,5,7,10,20}_*.data of the reference: n^3 unit cells of 8 ions, spacing 0.5,
+  // cells ordered x outermost, z innermost (verified against the files, tests/test_host.py)
+  static const double base[8][3] = {{0, 0, 0}, {.5, 0, 0}, {.5, .5, 0}, {0, .5, 0}, {.5, 0, .5}, {0, 0, .5}, {0, .5, .5}, {.5, .5, .5}};
+  std::vector<double> x;
+  q.clear();
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      for (int c = 0; c < n; ++c)
+        for (int k = 0; k < 8; ++k) {
+          x.push_back(base[k][0] + a); x.push_back(base[k][1] + b); x.push_back(base[k][2] + c);
+          q.push_back(k % 2 == 0 ? 1.0 : -1.0);
+        }
+  return x;
+}
+
+// ======================================================================== atoms
+
+template <int dim>
+struct LaplaceProblem<dim>::AtomBins {
+  double lo[3] = {0, 0, 0}, size = 1;
+  int n[3] = {1, 1, 1};
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> items;
+};
+
+template <int dim>
+LaplaceProblem<dim>::LaplaceProblem(const Parameters &p) : par(p) {
+  if (p.degree != 1) throw std::runtime_error("only Q1 elements (Polynomial degree = 1) are supported");
+  pcout("Problem type is:   " + par.Problemtype);
+  pcout("Preconditioner :    " + par.PreconditionerType);
+  pcout(par.flag_rhs_assembly ? "Rhs assembly optimization ENABLED" : "Without rhs assembly optimization");
+}
+
+template <int dim>
+LaplaceProblem<dim>::~LaplaceProblem() {
+  if (gmg) {
+    if (d_solution) gmg_vec_free(gmg, d_solution);
+    if (d_rhs) gmg_vec_free(gmg, d_rhs);
+    gmg_destroy(gmg);
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::pcout(const std::string &s) {
+  log += s;
+  log += '\n';
+  if (echo) std::cout << s << std::endl;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::read_lammps_input_file(const std::string &filename) {
+  // token-counting reader of :181-258: token #2 = number of atoms, token #35 starts the records
+  if (dim != 3) {
+    lammpsinput = false;
+    pcout("\nReading of Lammps input file implemented for 3D only\n");
+    return;
+  }
+  std::ifstream file(filename);
+  if (!file.is_open()) {
+    lammpsinput = false;
+    pcout("Unable to open the file.");
+    return;
+  }
+  lammpsinput = true;
+  std::string tok;
+  unsigned int count = 0;
+  while (!file.eof()) {
+    if (count == 2) {
+      file >> number_of_atoms;
+      pcout("Number of atoms: " + std::to_string(number_of_atoms));
+      charges.resize(number_of_atoms);
+      atom_positions.resize(3 * (size_t)number_of_atoms);
+    } else if (count == 35) {
+      for (unsigned int i = 0; i < number_of_atoms; ++i) {
+        double a, b, type;
+        file >> a >> b >> type >> charges[i] >> atom_positions[3 * i] >> atom_positions[3 * i + 1] >> atom_positions[3 * i + 2];
+      }
+    } else {
+      file >> tok;
+    }
+    ++count;
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::set_atoms(const std::vector<double> &q, const std::vector<double> &xyz) {
+  charges = q;
+  atom_positions = xyz;
+  number_of_atoms = (unsigned)q.size();
+  lammpsinput = true;
+  pcout("Number of atoms: " + std::to_string(number_of_atoms));
+}
+
+template <int dim>
+void LaplaceProblem<dim>::rhs_assembly_optimization() {
+  // :260-306 keeps, per cell, the atoms with ANY cell vertex closer than cutoff * r_c; children
+  // inherit the list unchanged (:441-450), so the list is a function of the root cell alone.
+  // Instead of the O(cells x atoms) scan the atoms are binned once; atoms_of_root_cell()
+  // evaluates the same predicate on the candidates of the neighbouring bins.
+  bins.reset(new AtomBins());
+  AtomBins &B = *bins;
+  const double cut = par.nonzero_density_radius_parameter * par.r_c;
+  double hi[3];
+  for (int d = 0; d < 3; ++d) { B.lo[d] = 1e300; hi[d] = -1e300; }
+  for (unsigned i = 0; i < number_of_atoms; ++i)
+    for (int d = 0; d < 3; ++d) {
+      B.lo[d] = std::min(B.lo[d], atom_positions[3 * i + (size_t)d]);
+      hi[d] = std::max(hi[d], atom_positions[3 * i + (size_t)d]);
+    }
+  B.size = std::max(cut, 1e-12);
+  int64_t total = 1;
+  for (int d = 0; d < 3; ++d) { B.n[d] = std::max(1, (int)std::floor((hi[d] - B.lo[d]) / B.size) + 1); total *= B.n[d]; }
+  B.ptr.assign((size_t)total + 1, 0);
+  auto bin_of = [&](unsigned i) {
+    int b[3];
+    for (int d = 0; d < 3; ++d) b[d] = std::min(B.n[d] - 1, std::max(0, (int)std::floor((atom_positions[3 * i + (size_t)d] - B.lo[d]) / B.size)));
+    return (int64_t)b[0] + B.n[0] * ((int64_t)b[1] + (int64_t)B.n[1] * b[2]);
+  };
+  for (unsigned i = 0; i < number_of_atoms; ++i) B.ptr[(size_t)bin_of(i) + 1]++;
+  for (int64_t b = 0; b < total; ++b) B.ptr[(size_t)b + 1] += B.ptr[(size_t)b];
+  B.items.resize(number_of_atoms);
+  std::vector<int64_t> pos(B.ptr.begin(), B.ptr.end() - 1);
+  for (unsigned i = 0; i < number_of_atoms; ++i) B.items[(size_t)pos[(size_t)bin_of(i)]++] = (int32_t)i;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::atoms_of_root_cell(const int rc[3], std::vector<int32_t> &out) const {
+  out.clear();
+  const AtomBins &B = *bins;
+  const double cut = par.nonzero_density_radius_parameter * par.r_c;
+  const double h = triangulation.h0;
+  double lo[3], hi[3];
+  int b0[3], b1[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = triangulation.origin + h * rc[d];
+    hi[d] = triangulation.origin + h * (rc[d] + 1);
+    b0[d] = (int)std::floor((lo[d] - cut - B.lo[d]) / B.size);
+    b1[d] = (int)std::floor((hi[d] + cut - B.lo[d]) / B.size);
+    b0[d] = std::max(b0[d], 0);
+    b1[d] = std::min(b1[d], B.n[d] - 1);
+  }
+  for (int z = b0[2]; z <= b1[2]; ++z)
+    for (int y = b0[1]; y <= b1[1]; ++y)
+      for (int x = b0[0]; x <= b1[0]; ++x) {
+        const int64_t b = (int64_t)x + B.n[0] * ((int64_t)y + (int64_t)B.n[1] * z);
+        for (int64_t k = B.ptr[(size_t)b]; k < B.ptr[(size_t)b + 1]; ++k) {
+          const int32_t i = B.items[(size_t)k];
+          double d2 = 0;
+          for (int d = 0; d < 3; ++d) {  // nearest vertex, direction by direction
+            const double a = atom_positions[3 * (size_t)i + (size_t)d];
+            const double dl = a - lo[d], dh = a - hi[d];
+            const double m = std::fabs(dl) <= std::fabs(dh) ? dl : dh;
+            d2 += m * m;
+          }
+          if (std::sqrt(d2) < cut) out.push_back(i);
+        }
+      }
+  std::sort(out.begin(), out.end());  // std::set iteration order of the reference (:559-560)
+}
+
+// ======================================================================== problem functions
+
+template <int dim>
+double LaplaceProblem<dim>::coefficient(const double x[3]) const {
+  if (par.Problemtype == "Step16") {  // include/step_50.h:246-254
+    double s = 0;
+    for (int d = 0; d < dim; ++d) s += x[d] * x[d];
+    return s < 0.25 ? 5.0 : 1.0;
+  }
+  return 1.0;
+}
+
+template <int dim>
+double LaplaceProblem<dim>::rhs_function(const double x[3]) const {
+  if (par.Problemtype == "Step16") return 10.0;  // include/step_50.h:240-244
+  double s = 0;                                   // include/step_50.h:321-329
+  for (int d = 0; d < dim; ++d) s += x[d] * x[d];
+  const double c = s / (par.r_c * par.r_c);
+  return (8.0 * std::exp(-4.0 * c) - std::exp(-c)) / (std::pow(par.r_c, 3) * std::pow(M_PI, 1.5));
+}
+
+template <int dim>
+double LaplaceProblem<dim>::boundary_value(const double x[3]) const {
+  if (par.Boundary_conditions == "Homogeneous") return 0.0;
+  if (par.Boundary_conditions == "Exact") {  // Analytical_Solution::value, include/step_50.h:338-353
+    if (par.Problemtype != "GaussianCharges") return 0.0;
+    double v = 0;
+    const double inv = 1.0 / (std::sqrt(M_PI) * par.r_c);
+    for (unsigned i = 0; i < number_of_atoms; ++i) {
+      double r2 = 0;
+      for (int d = 0; d < dim; ++d) { const double t = x[d] - atom_positions[3 * i + (size_t)d]; r2 += t * t; }
+      const double r = std::sqrt(r2);
+      v += r < 1e-10 ? charges[i] * 2.0 * inv : charges[i] * (std::erf(r / par.r_c) / r);
+    }
+    return v;
+  }
+  // Inhomogeneous: NonZeroDBC with x0 = 0, dipole p0, quadrupole forced to 0 (:623-624, step_50.h:378-385)
+  double r2 = 0, px = 0;
+  for (int d = 0; d < dim; ++d) { r2 += x[d] * x[d]; px += dipole_moment[d] * x[d]; }
+  const double r = std::sqrt(r2);
+  return px / std::pow(r, 3) + (0.5 * 0.0) / std::pow(r, 5);
+}
+
+// ======================================================================== mesh + DoFs
+
+template <int dim>
+void LaplaceProblem<dim>::make_initial_grid() {
+  if (par.Problemtype == "Step16") {  // :1496-1497
+    triangulation.create_lattice(1, par.domain_size_left, par.domain_size_right - par.domain_size_left);
+    triangulation.refine_global((int)par.number_of_global_refinement);
+  } else {  // :1504-1526
+    const double a = 2 * par.mesh_size_h;
+    const double N = (par.domain_size_right - par.domain_size_left) / a;
+    const double M = par.repetitions_for_vacuum;
+    const unsigned int reps = (unsigned int)(2 * (N + 2 * M));
+    const double lo = par.domain_size_left - M * a, hi = par.domain_size_right + M * a;
+    if (std::pow((double)reps, dim) > 2.0e8) throw std::runtime_error("initial lattice too large for this host");
+    // "Need to set #Global_ref = 0" (:1503): the reference applies no global refinement here
+    triangulation.create_lattice((int)reps, lo, (hi - lo) / reps);
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::cell_dofs(const ActiveCell &c, int32_t *out) const {
+  const Cell &cell = triangulation.levels[(size_t)c.level][(size_t)c.index];
+  for (int a = 0; a < (1 << dim); ++a) out[a] = dof_of_vertex.at(triangulation.vertex_key(c.level, cell, a));
+}
+template <int dim>
+void LaplaceProblem<dim>::level_cell_dofs(int level, int32_t ci, int32_t *out) const {
+  const Cell &cell = triangulation.levels[(size_t)level][(size_t)ci];
+  for (int a = 0; a < (1 << dim); ++a) out[a] = level_dof_of_vertex[(size_t)level].at(triangulation.vertex_key(level, cell, a));
+}
+
+template <int dim>
+void LaplaceProblem<dim>::distribute_dofs() {
+  // DoFs are numbered in the order cells meet their vertices: active cells by (level, index) for
+  // the active mesh, all cells of a level by index for the level DoFs.
+  const int L = triangulation.n_levels();
+  active_cells.clear();
+  active_index_of_cell.assign((size_t)L, {});
+  for (int l = 0; l < L; ++l) {
+    active_index_of_cell[(size_t)l].assign(triangulation.levels[(size_t)l].size(), -1);
+    for (size_t c = 0; c < triangulation.levels[(size_t)l].size(); ++c)
+      if (triangulation.levels[(size_t)l][c].first_child < 0) {
+        active_index_of_cell[(size_t)l][c] = (int32_t)active_cells.size();
+        active_cells.push_back({l, (int32_t)c});
+      }
+  }
+  dof_of_vertex.clear();
+  vertex_of_dof.clear();
+  dof_of_vertex.reserve(active_cells.size() * 2);
+  for (const ActiveCell &ac : active_cells) {
+    const Cell &cell = triangulation.levels[(size_t)ac.level][(size_t)ac.index];
+    for (int a = 0; a < (1 << dim); ++a) {
+      const uint64_t key = triangulation.vertex_key(ac.level, cell, a);
+      if (dof_of_vertex.emplace(key, (int32_t)vertex_of_dof.size()).second) vertex_of_dof.push_back(key);
+    }
+  }
+  level_dof_of_vertex.assign((size_t)L, {});
+  level_vertex_of_dof.assign((size_t)L, {});
+  for (int l = 0; l < L; ++l) {
+    auto &map = level_dof_of_vertex[(size_t)l];
+    auto &vec = level_vertex_of_dof[(size_t)l];
+    map.reserve(triangulation.levels[(size_t)l].size() * 2);
+    for (const Cell &cell : triangulation.levels[(size_t)l])
+      for (int a = 0; a < (1 << dim); ++a) {
+        const uint64_t key = triangulation.vertex_key(l, cell, a);
+        if (map.emplace(key, (int32_t)vec.size()).second) vec.push_back(key);
+      }
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::make_constraints() {
+  // DoFTools::make_hanging_node_constraints + VectorTools::interpolate_boundary_values +
+  // constraints.close() (:661-696), and MGConstrainedDoFs (:704-706).
+  const int64_t n = (int64_t)vertex_of_dof.size();
+  constraint_of_dof.assign((size_t)n, -1);
+  constraint_lines.clear();
+  const int shift0 = kMaxLevelShift;
+  for (const ActiveCell &ac : active_cells) {
+    const int l = ac.level;
+    const Cell &c = triangulation.levels[(size_t)l][(size_t)ac.index];
+    for (int d = 0; d < dim; ++d)
+      for (int side = 0; side < 2; ++side) {
+        int nb[3] = {c.c[0], c.c[1], c.c[2]};
+        nb[d] += side ? 1 : -1;
+        const int32_t N = triangulation.find(l, nb[0], nb[1], nb[2]);
+        if (N < 0 || triangulation.active(l, N)) continue;
+        // the face of this coarse cell is refined on the other side: its centre and edge
+        // mid-points are hanging nodes
+        uint64_t corner[4][3];
+        int nc = 0;
+        for (int a = 0; a < (1 << dim); ++a)
+          if (((a >> d) & 1) == side) {
+            uint64_t v[3];
+            Forest<dim>::unpack(triangulation.vertex_key(l, c, a), v);
+            for (int e = 0; e < 3; ++e) corner[nc][e] = v[e];
+            ++nc;
+          }
+        auto add_line = [&](const int *ids, int m) {
+          uint64_t s[3] = {0, 0, 0};
+          for (int q = 0; q < m; ++q)
+            for (int e = 0; e < 3; ++e) s[e] += corner[ids[q]][e];
+          const uint64_t key = pack3(s[0] / (uint64_t)m, s[1] / (uint64_t)m, s[2] / (uint64_t)m);
+          auto it = dof_of_vertex.find(key);
+          if (it == dof_of_vertex.end()) throw std::logic_error("hanging node without a DoF: mesh is not 2:1 balanced");
+          if (constraint_of_dof[(size_t)it->second] >= 0) return;
+          ConstraintLine line;
+          line.hanging = true;
+          for (int q = 0; q < m; ++q)
+            line.entries.push_back({dof_of_vertex.at(pack3(corner[ids[q]][0], corner[ids[q]][1], corner[ids[q]][2])), 1.0 / m});
+          constraint_of_dof[(size_t)it->second] = (int32_t)constraint_lines.size();
+          constraint_lines.push_back(line);
+        };
+        if (dim == 2) {
+          const int e[2] = {0, 1};
+          add_line(e, 2);
+        } else {
+          const int all[4] = {0, 1, 2, 3};
+          add_line(all, 4);
+          const int edges[4][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}};
+          for (auto &e : edges) add_line(e, 2);
+        }
+      }
+  }
+  (void)shift0;
+  // Dirichlet lines for boundary DoFs that are not already (hanging-node) constrained
+  if (lammpsinput) compute_moments();
+  for (int64_t i = 0; i < n; ++i) {
+    if (!triangulation.vertex_on_boundary(vertex_of_dof[(size_t)i]) || constraint_of_dof[(size_t)i] >= 0) continue;
+    double x[3];
+    triangulation.vertex_coords(vertex_of_dof[(size_t)i], x);
+    ConstraintLine line;
+    line.inhomogeneity = boundary_value(x);
+    constraint_of_dof[(size_t)i] = (int32_t)constraint_lines.size();
+    constraint_lines.push_back(line);
+  }
+  // close(): masters that are themselves (Dirichlet) constrained fold into the inhomogeneity
+  for (ConstraintLine &line : constraint_lines) {
+    if (!line.hanging) continue;
+    std::vector<std::pair<int32_t, double>> kept;
+    for (auto &e : line.entries) {
+      const int32_t cm = constraint_of_dof[(size_t)e.first];
+      if (cm < 0) { kept.push_back(e); continue; }
+      const ConstraintLine &m = constraint_lines[(size_t)cm];
+      if (m.hanging) throw std::logic_error("hanging node constrained to a hanging node");
+      line.inhomogeneity += e.second * m.inhomogeneity;
+    }
+    line.entries.swap(kept);
+  }
+  // MGConstrainedDoFs: boundary indices and refinement-edge indices per level
+  const int L = triangulation.n_levels();
+  level_boundary.assign((size_t)L, {});
+  level_refinement_edge.assign((size_t)L, {});
+  for (int l = 0; l < L; ++l) {
+    const auto &vec = level_vertex_of_dof[(size_t)l];
+    level_boundary[(size_t)l].assign(vec.size(), 0);
+    level_refinement_edge[(size_t)l].assign(vec.size(), 0);
+    for (size_t i = 0; i < vec.size(); ++i) level_boundary[(size_t)l][i] = triangulation.vertex_on_boundary(vec[i]);
+    if (l == 0) continue;
+    const int nl = triangulation.n0 << l;
+    for (size_t ci = 0; ci < triangulation.levels[(size_t)l].size(); ++ci) {
+      const Cell &c = triangulation.levels[(size_t)l][ci];
+      for (int d = 0; d < dim; ++d)
+        for (int side = 0; side < 2; ++side) {
+          int nb[3] = {c.c[0], c.c[1], c.c[2]};
+          nb[d] += side ? 1 : -1;
+          if (nb[d] < 0 || nb[d] >= nl) continue;  // domain boundary
+          if (triangulation.find(l, nb[0], nb[1], nb[2]) >= 0) continue;
+          for (int a = 0; a < (1 << dim); ++a)
+            if (((a >> d) & 1) == side)
+              level_refinement_edge[(size_t)l][(size_t)level_dof_of_vertex[(size_t)l].at(triangulation.vertex_key(l, c, a))] = 1;
+        }
+    }
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::setup_system(unsigned int cycle) {
+  distribute_dofs();
+  const int64_t n = (int64_t)vertex_of_dof.size();
+  solution.assign((size_t)n, 0.0);
+  system_rhs.assign((size_t)n, 0.0);
+  if (cycle == 0 && par.flag_rhs_assembly && lammpsinput) rhs_assembly_optimization();
+  if (lammpsinput) compute_charge_densities();
+  make_constraints();  // calls compute_moments() first when atoms are present (:675-679)
+}
+
+template <int dim>
+void LaplaceProblem<dim>::compute_charge_densities() {
+  // :509-575, rho(x_q) = 4 pi / (r_c^3 pi^1.5) sum_k q_k exp(-|x_q - x_k|^2 / r_c^2)
+  const Quadrature<dim> quad((int)(par.degree + par.quadrature_degree_rhs));
+  const size_t nq = quad.p.size();
+  density_values_for_each_cell.assign(active_cells.size(), {});
+  const double constant_value = 4.0 * M_PI / (std::pow(par.r_c, 3) * std::pow(M_PI, 1.5));
+  const double r_c_squared_inverse = 1.0 / (par.r_c * par.r_c);
+#pragma omp parallel
+  {
+    std::vector<int32_t> atoms;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t ci = 0; ci < (int64_t)active_cells.size(); ++ci) {
+      const ActiveCell &ac = active_cells[(size_t)ci];
+      const Cell &cell = triangulation.levels[(size_t)ac.level][(size_t)ac.index];
+      double x0[3];
+      triangulation.cell_origin(ac.level, cell, x0);
+      const double h = triangulation.cell_size(ac.level);
+      const bool use_list = par.flag_rhs_assembly;
+      if (use_list) {
+        const int rc[3] = {cell.c[0] >> ac.level, cell.c[1] >> ac.level, cell.c[2] >> ac.level};
+        atoms_of_root_cell(rc, atoms);
+      }
+      std::vector<double> &dens = density_values_for_each_cell[(size_t)ci];
+      dens.assign(nq, 0.0);
+      const size_t na = use_list ? atoms.size() : (size_t)number_of_atoms;
+      for (size_t q = 0; q < nq; ++q) {
+        double xq[3] = {0, 0, 0};
+        for (int d = 0; d < dim; ++d) xq[d] = x0[d] + h * quad.p[q][(size_t)d];
+        double s = 0.0;
+        for (size_t t = 0; t < na; ++t) {
+          const size_t k = use_list ? (size_t)atoms[t] : t;
+          double r2 = 0;
+          for (int d = 0; d < 3; ++d) { const double dd = atom_positions[3 * k + (size_t)d] - xq[d]; r2 += dd * dd; }
+          const double r = std::sqrt(r2);  // the reference squares the distance again (:547-548)
+          s += constant_value * std::exp(-(r * r) * r_c_squared_inverse) * charges[k];
+        }
+        dens[q] = s;
+      }
+    }
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::compute_moments() {
+  // :577-644 -- the quadrupole is integrated and then overwritten with 0 (:623-624): only the
+  // dipole survives.
+  for (int d = 0; d < 3; ++d) dipole_moment[d] = 0;
+  for (unsigned k = 0; k < number_of_atoms; ++k)
+    for (int d = 0; d < 3; ++d) dipole_moment[d] += charges[k] * atom_positions[3 * k + (size_t)d];
+}
+
+// ======================================================================== assembly
+
+namespace {
+template <int dim, class Coef>
+void cell_matrix(const Quadrature<dim> &q2, double h, const double x0[3], Coef coef, bool constant, double K[1 << dim][1 << dim]) {
+  constexpr int nv = 1 << dim;
+  for (int i = 0; i < nv; ++i)
+    for (int j = 0; j < nv; ++j) K[i][j] = 0;
+  const double scale = std::pow(h, dim - 2);  // JxW / h^2 from the two gradients
+  for (size_t q = 0; q < q2.p.size(); ++q) {
+    double c = 1.0;
+    if (!constant) {
+      double x[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) x[d] = x0[d] + h * q2.p[q][(size_t)d];
+      c = coef(x);
+    }
+    for (int i = 0; i < nv; ++i)
+      for (int j = 0; j < nv; ++j) {
+        double g = 0;
+        for (int d = 0; d < dim; ++d) g += q2.grad[q][(size_t)i][(size_t)d] * q2.grad[q][(size_t)j][(size_t)d];
+        K[i][j] += c * g * q2.w[q] * scale;
+      }
+  }
+}
+}  // namespace
+
+template <int dim>
+void LaplaceProblem<dim>::assemble_system() {
+  constexpr int nv = 1 << dim;
+  const int64_t n = (int64_t)vertex_of_dof.size();
+  const Quadrature<dim> q_laplace((int)par.degree + 1), q_rhs((int)(par.degree + par.quadrature_degree_rhs));
+  const bool constant_coef = par.Problemtype != "Step16";
+  // coupling lists: the cell's DoFs plus the masters of its constrained DoFs
+  std::vector<int64_t> cptr(active_cells.size() + 1, 0);
+  std::vector<int32_t> citems;
+  citems.reserve(active_cells.size() * nv);
+  for (size_t ci = 0; ci < active_cells.size(); ++ci) {
+    int32_t dofs[nv];
+    cell_dofs(active_cells[ci], dofs);
+    const size_t begin = citems.size();
+    for (int a = 0; a < nv; ++a) {
+      citems.push_back(dofs[a]);
+      const int32_t cl = constraint_of_dof[(size_t)dofs[a]];
+      if (cl >= 0)
+        for (auto &e : constraint_lines[(size_t)cl].entries) citems.push_back(e.first);
+    }
+    std::sort(citems.begin() + (std::ptrdiff_t)begin, citems.end());
+    citems.erase(std::unique(citems.begin() + (std::ptrdiff_t)begin, citems.end()), citems.end());
+    cptr[ci + 1] = (int64_t)citems.size();
+  }
+  system_matrix = pattern_from_cells(n, cptr, citems);
+  system_rhs.assign((size_t)n, 0.0);
+
+  double Kc[nv][nv];
+  if (constant_coef) {
+    double x0[3] = {0, 0, 0};
+    cell_matrix<dim>(q_laplace, 1.0, x0, [&](const double *) { return 1.0; }, true, Kc);
+  }
+  for (size_t ci = 0; ci < active_cells.size(); ++ci) {
+    const ActiveCell &ac = active_cells[ci];
+    const Cell &cell = triangulation.levels[(size_t)ac.level][(size_t)ac.index];
+    const double h = triangulation.cell_size(ac.level);
+    double x0[3];
+    triangulation.cell_origin(ac.level, cell, x0);
+    double K[nv][nv];
+    if (constant_coef) {
+      const double s = std::pow(h, dim - 2);
+      for (int i = 0; i < nv; ++i)
+        for (int j = 0; j < nv; ++j) K[i][j] = Kc[i][j] * s;
+    } else {
+      cell_matrix<dim>(q_laplace, h, x0, [&](const double *x) { return coefficient(x); }, false, K);
+    }
+    double F[nv];
+    for (int i = 0; i < nv; ++i) F[i] = 0;
+    const double jxw = std::pow(h, dim);
+    for (size_t q = 0; q < q_rhs.p.size(); ++q) {
+      double dens;
+      if (lammpsinput) dens = density_values_for_each_cell[ci][q];
+      else {
+        double x[3] = {0, 0, 0};
+        for (int d = 0; d < dim; ++d) x[d] = x0[d] + h * q_rhs.p[q][(size_t)d];
+        dens = rhs_function(x);
+      }
+      for (int i = 0; i < nv; ++i) F[i] += q_rhs.shape[q][(size_t)i] * dens * q_rhs.w[q] * jxw;
+    }
+    int32_t dofs[nv];
+    cell_dofs(ac, dofs);
+    // ConstraintMatrix::distribute_local_to_global (:793-795, 825-828)
+    const ConstraintLine *line[nv];
+    for (int a = 0; a < nv; ++a) {
+      const int32_t cl = constraint_of_dof[(size_t)dofs[a]];
+      line[a] = cl >= 0 ? &constraint_lines[(size_t)cl] : nullptr;
+    }
+    for (int i = 0; i < nv; ++i) {
+      double Fi = F[i];
+      for (int j = 0; j < nv; ++j)
+        if (line[j] && line[j]->inhomogeneity != 0.0) Fi -= K[i][j] * line[j]->inhomogeneity;
+      if (line[i]) {
+        system_matrix.add(dofs[i], dofs[i], std::fabs(K[i][i]));
+        for (auto &ri : line[i]->entries) system_rhs[(size_t)ri.first] += ri.second * Fi;
+      } else {
+        system_rhs[(size_t)dofs[i]] += Fi;
+      }
+      for (int j = 0; j < nv; ++j) {
+        if (!line[i] && !line[j]) { system_matrix.add(dofs[i], dofs[j], K[i][j]); continue; }
+        if (line[i] && line[i]->entries.empty()) continue;
+        if (line[j] && line[j]->entries.empty()) continue;
+        if (line[i] && line[j]) {
+          for (auto &ri : line[i]->entries)
+            for (auto &rj : line[j]->entries) system_matrix.add(ri.first, rj.first, ri.second * rj.second * K[i][j]);
+        } else if (line[i]) {
+          for (auto &ri : line[i]->entries) system_matrix.add(ri.first, dofs[j], ri.second * K[i][j]);
+        } else {
+          for (auto &rj : line[j]->entries) system_matrix.add(dofs[i], rj.first, rj.second * K[i][j]);
+        }
+      }
+    }
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::assemble_multigrid() {
+  constexpr int nv = 1 << dim;
+  const int L = triangulation.n_levels();
+  const Quadrature<dim> q_laplace((int)par.degree + 1);
+  const bool constant_coef = par.Problemtype != "Step16";
+  mg_matrices.assign((size_t)L, {});
+  mg_interface_matrices.assign((size_t)L, {});
+  double Kc[nv][nv];
+  if (constant_coef) {
+    double x0[3] = {0, 0, 0};
+    cell_matrix<dim>(q_laplace, 1.0, x0, [&](const double *) { return 1.0; }, true, Kc);
+  }
+  for (int l = 0; l < L; ++l) {
+    const auto &cells = triangulation.levels[(size_t)l];
+    const int64_t n = (int64_t)level_vertex_of_dof[(size_t)l].size();
+    std::vector<int64_t> cptr(cells.size() + 1, 0);
+    std::vector<int32_t> citems(cells.size() * nv);
+    for (size_t ci = 0; ci < cells.size(); ++ci) {
+      level_cell_dofs(l, (int32_t)ci, &citems[ci * nv]);
+      cptr[ci + 1] = (int64_t)(ci + 1) * nv;
+    }
+    CSRMatrix &A = mg_matrices[(size_t)l];
+    A = pattern_from_cells(n, cptr, citems);
+    const auto &bnd = level_boundary[(size_t)l];
+    const auto &edge = level_refinement_edge[(size_t)l];
+    std::vector<std::array<int64_t, 2>> irc;
+    std::vector<double> iv;
+    const double h = triangulation.cell_size(l);
+    for (size_t ci = 0; ci < cells.size(); ++ci) {
+      double K[nv][nv];
+      if (constant_coef) {
+        const double s = std::pow(h, dim - 2);
+        for (int i = 0; i < nv; ++i)
+          for (int j = 0; j < nv; ++j) K[i][j] = Kc[i][j] * s;
+      } else {
+        double x0[3];
+        triangulation.cell_origin(l, cells[ci], x0);
+        cell_matrix<dim>(q_laplace, h, x0, [&](const double *x) { return coefficient(x); }, false, K);
+      }
+      const int32_t *dofs = &citems[ci * nv];
+      for (int i = 0; i < nv; ++i) {
+        const bool ci_ = bnd[(size_t)dofs[i]] || edge[(size_t)dofs[i]];
+        if (ci_) { A.add(dofs[i], dofs[i], std::fabs(K[i][i])); continue; }
+        for (int j = 0; j < nv; ++j) {
+          const bool cj = bnd[(size_t)dofs[j]] || edge[(size_t)dofs[j]];
+          if (!cj) A.add(dofs[i], dofs[j], K[i][j]);
+        }
+      }
+      // interface ("edge") matrix, :892-925: i on the refinement edge, j not, neither on the boundary
+      for (int i = 0; i < nv; ++i) {
+        if (!edge[(size_t)dofs[i]] || bnd[(size_t)dofs[i]]) continue;
+        for (int j = 0; j < nv; ++j)
+          if (!edge[(size_t)dofs[j]] && !bnd[(size_t)dofs[j]]) {
+            irc.push_back({dofs[i], dofs[j]});
+            iv.push_back(K[i][j]);
+          }
+      }
+    }
+    mg_interface_matrices[(size_t)l] = csr_from_triplets(n, n, irc, iv, true);
+  }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::build_transfer() {
+  // MGTransferPrebuilt::build_matrices (:957-958): Q1 embedding per child, columns of coarse
+  // boundary DoFs zeroed; copy_indices for PreconditionMG (active cells, not on the refinement edge)
+  constexpr int nv = 1 << dim;
+  const int L = triangulation.n_levels();
+  mg_prolongation.assign((size_t)std::max(0, L - 1), {});
+  for (int l = 0; l + 1 < L; ++l) {
+    std::vector<std::array<int64_t, 2>> rc;
+    std::vector<double> v;
+    const auto &cells = triangulation.levels[(size_t)l];
+    for (size_t ci = 0; ci < cells.size(); ++ci) {
+      if (cells[ci].first_child < 0) continue;
+      int32_t pd[nv];
+      level_cell_dofs(l, (int32_t)ci, pd);
+      for (int a = 0; a < nv; ++a) {
+        int32_t cd[nv];
+        level_cell_dofs(l + 1, cells[ci].first_child + a, cd);
+        for (int b = 0; b < nv; ++b)
+          for (int p = 0; p < nv; ++p) {
+            double w = 1;
+            for (int d = 0; d < dim; ++d) {
+              const double pos = 0.5 * (((a >> d) & 1) + ((b >> d) & 1));
+              w *= ((p >> d) & 1) ? pos : 1.0 - pos;
+            }
+            if (w == 0.0 || level_boundary[(size_t)l][(size_t)pd[p]]) continue;
+            rc.push_back({cd[b], pd[p]});
+            v.push_back(w);
+          }
+      }
+    }
+    mg_prolongation[(size_t)l] =
+        csr_from_triplets((int64_t)level_vertex_of_dof[(size_t)l + 1].size(), (int64_t)level_vertex_of_dof[(size_t)l].size(), rc, v, false);
+  }
+  copy_global.assign((size_t)L, {});
+  copy_level.assign((size_t)L, {});
+  for (int l = 0; l < L; ++l) {
+    std::vector<char> seen(level_vertex_of_dof[(size_t)l].size(), 0);
+    for (const ActiveCell &ac : active_cells) {
+      if (ac.level != l) continue;
+      const Cell &cell = triangulation.levels[(size_t)l][(size_t)ac.index];
+      for (int a = 0; a < nv; ++a) {
+        const uint64_t key = triangulation.vertex_key(l, cell, a);
+        const int32_t ld = level_dof_of_vertex[(size_t)l].at(key);
+        if (seen[(size_t)ld] || level_refinement_edge[(size_t)l][(size_t)ld]) continue;
+        seen[(size_t)ld] = 1;
+        copy_global[(size_t)l].push_back(dof_of_vertex.at(key));
+        copy_level[(size_t)l].push_back(ld);
+      }
+    }
+  }
+}
+
+// ======================================================================== device hand-over + solve
+
+#define GMGC(call)                                                    \
+  do {                                                                \
+    const int rc_ = (call);                                           \
+    if (rc_ != GMG_OK) {                                              \
+      last_error = std::string(#call) + ": " + (gmg ? gmg_last_error(gmg) : "no context"); \
+      return rc_;                                                     \
+    }                                                                 \
+  } while (0)
+
+template <int dim>
+int LaplaceProblem<dim>::upload() {
+  const int L = triangulation.n_levels();
+  if (gmg) {
+    if (d_solution) gmg_vec_free(gmg, d_solution);
+    if (d_rhs) gmg_vec_free(gmg, d_rhs);
+    d_solution = d_rhs = nullptr;
+    gmg_destroy(gmg);
+    gmg = nullptr;
+  }
+  const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
+  int rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
+  if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
+  const CSRMatrix &S = system_matrix;
+  GMGC(gmg_set_system_matrix(gmg, S.n_rows, S.n_cols, S.rowptr.data(), S.col.data(), S.val.data()));
+  for (int l = 0; l < L; ++l) {
+    const CSRMatrix &A = mg_matrices[(size_t)l];
+    GMGC(gmg_set_level_matrix(gmg, l, A.n_rows, A.n_cols, A.rowptr.data(), A.col.data(), A.val.data()));
+    const CSRMatrix &I = mg_interface_matrices[(size_t)l];
+    if (I.nnz() > 0) GMGC(gmg_set_edge_matrix(gmg, l, I.n_rows, I.n_cols, I.rowptr.data(), I.col.data(), I.val.data()));
+    GMGC(gmg_set_copy_indices(gmg, l, (int64_t)copy_global[(size_t)l].size(), copy_global[(size_t)l].data(), copy_level[(size_t)l].data()));
+    if (l + 1 < L) {
+      const CSRMatrix &P = mg_prolongation[(size_t)l];
+      GMGC(gmg_set_prolongation(gmg, l, P.n_rows, P.n_cols, P.rowptr.data(), P.col.data(), P.val.data()));
+    }
+  }
+  const int kind = par.smoother == "Jacobi" ? GMG_SMOOTHER_JACOBI : par.smoother == "Chebyshev" ? GMG_SMOOTHER_CHEBYSHEV : GMG_SMOOTHER_SSOR;
+  GMGC(gmg_set_smoother(gmg, kind, par.smoother_omega, par.smoother_steps, par.chebyshev_degree, 0.0, 0.0));
+  GMGC(gmg_set_coarse(gmg, 1e-10, 1000));  // :962
+  d_n = S.n_rows;
+  GMGC(gmg_vec_alloc(gmg, d_n, &d_solution));
+  GMGC(gmg_vec_alloc(gmg, d_n, &d_rhs));
+  GMGC(gmg_vec_upload(gmg, d_rhs, system_rhs.data(), d_n));
+  return GMG_OK;
+}
+
+int SolverCG_solve(gmg_context *ctx, SolverControl &control, int64_t n, int64_t n_vec, double *x, const double *b,
+                   const std::string &preconditioner) {
+  // deal.II SolverCG<vector_t>::solve; "GMG" -> PreconditionMG::vmult, "Jacobi" -> omega 0.6 (:996-1004)
+  double *g = nullptr, *d = nullptr, *h = nullptr;
+  int rc = GMG_OK;
+  if ((rc = gmg_vec_alloc(ctx, n_vec, &g)) || (rc = gmg_vec_alloc(ctx, n_vec, &d)) || (rc = gmg_vec_alloc(ctx, n_vec, &h))) return rc;
+  auto precondition = [&](double *dst, const double *src) {
+    return preconditioner == "GMG" ? gmg_precondition(ctx, dst, src) : gmg_precondition_jacobi(ctx, 0.6, dst, src);
+  };
+  int it = 0, zero = 0;
+  double res = 0, gh = 0, alpha = 0, beta = 0, tmp = 0;
+  do {
+    if ((rc = gmg_vec_all_zero(ctx, x, n, &zero))) break;
+    if (!zero) {
+      if ((rc = gmg_spmv(ctx, GMG_SYSTEM, g, x))) break;
+      gmg_vec_add(ctx, g, -1.0, b, n);
+    } else {
+      gmg_vec_equ(ctx, g, -1.0, b, n);
+    }
+    if ((rc = gmg_vec_dot(ctx, g, g, n, &tmp))) break;
+    res = std::sqrt(tmp);
+    control.initial_value = res;
+    if (res <= control.tolerance) break;
+    if ((rc = precondition(h, g))) break;
+    gmg_vec_equ(ctx, d, -1.0, h, n);
+    if ((rc = gmg_vec_dot(ctx, g, h, n, &gh))) break;
+    for (;;) {
+      ++it;
+      if ((rc = gmg_spmv(ctx, GMG_SYSTEM, h, d))) break;
+      if ((rc = gmg_vec_dot(ctx, d, h, n, &alpha))) break;
+      alpha = gh / alpha;
+      gmg_vec_add(ctx, x, alpha, d, n);
+      gmg_vec_add(ctx, g, alpha, h, n);
+      if ((rc = gmg_vec_dot(ctx, g, g, n, &tmp))) break;
+      res = std::sqrt(tmp);
+      if (res <= control.tolerance) break;
+      if (it >= control.max_steps || res != res) { rc = GMG_ERR_OUTER_NOCONV; break; }
+      if ((rc = precondition(h, g))) break;
+      beta = gh;
+      if ((rc = gmg_vec_dot(ctx, g, h, n, &gh))) break;
+      beta = gh / beta;
+      gmg_vec_sadd(ctx, d, beta, -1.0, h, n);
+    }
+  } while (0);
+  control.last_step = it;
+  control.last_value = res;
+  gmg_synchronize(ctx);
+  gmg_vec_free(ctx, g); gmg_vec_free(ctx, d); gmg_vec_free(ctx, h);
+  return rc;
+}
+
+template <int dim>
+int LaplaceProblem<dim>::solve_on_device(CycleReport &rep) {
+  GMGC(gmg_vec_upload(gmg, d_solution, initial_guess.data(), d_n));
+  gmg_stats st0;
+  gmg_stats_get(gmg, &st0);
+  double l1, l2, li;
+  GMGC(gmg_vec_norms(gmg, d_rhs, d_n, &l1, &l2, &li));  // system_rhs.l2_norm(), :942
+  SolverControl control{500, 1e-8 * l2};
+  GMGC(gmg_synchronize(gmg));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  if (par.device_resident_outer_cg) {
+    rc = gmg_cg_solve(gmg, d_solution, d_rhs, 1e-8, 500, par.PreconditionerType == "GMG" ? GMG_PRECOND_GMG : GMG_PRECOND_JACOBI,
+                      &control.last_step, &control.initial_value, &control.last_value);
+  } else {
+    rc = SolverCG_solve(gmg, control, d_n, d_n, d_solution, d_rhs, par.PreconditionerType);
+  }
+  gmg_synchronize(gmg);
+  rep.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  rep.starting_value = control.initial_value;
+  rep.cg_iterations = control.last_step;
+  rep.convergence_value = control.last_value;
+  rep.status = rc;
+  gmg_stats st;
+  gmg_stats_get(gmg, &st);
+  rep.coarse_iterations = st.coarse_iterations - st0.coarse_iterations;
+  if (rc != GMG_OK) { last_error = std::string("solve: ") + gmg_last_error(gmg); return rc; }
+  GMGC(gmg_vec_norms(gmg, d_solution, d_n, &rep.sol_l1, &rep.sol_l2, &rep.sol_linf));  // :1012-1014
+  GMGC(gmg_vec_download(gmg, solution.data(), d_solution, d_n));
+  return GMG_OK;
+}
+
+template <int dim>
+int LaplaceProblem<dim>::solve() {
+  // :938-1017.  The operators were handed over by upload(); this is the timed hot path.
+  CycleReport &rep = reports.back();
+  rep.rhs_l1 = rep.rhs_l2 = rep.rhs_linf = 0;
+  for (double v : system_rhs) { rep.rhs_l1 += std::fabs(v); rep.rhs_l2 += v * v; rep.rhs_linf = std::max(rep.rhs_linf, std::fabs(v)); }
+  rep.rhs_l2 = std::sqrt(rep.rhs_l2);
+  rep.matrix_l1 = system_matrix.l1_norm();
+  rep.matrix_linf = system_matrix.linfty_norm();
+  rep.matrix_frobenius = system_matrix.frobenius_norm();
+  pcout("   L1 rhs norm " + fmt("%.10e", rep.rhs_l1));
+  pcout("   L2 rhs norm " + fmt("%.10e", rep.rhs_l2));
+  pcout("   LInfinity rhs norm " + fmt("%.10e", rep.rhs_linf));
+  pcout("   L1 Matrix norm " + fmt("%.10e", rep.matrix_l1));
+  pcout("   LInfinity Matrix norm " + fmt("%.10e", rep.matrix_linf));
+  pcout("   Frobenius Matrix norm " + fmt("%.10e", rep.matrix_frobenius));
+  const int rc = solve_on_device(rep);
+  if (rc != GMG_OK) return rc;
+  pcout("   Starting value " + fmt("%.10f", rep.starting_value));
+  pcout("   CG converged in " + std::to_string(rep.cg_iterations) + " iterations.");
+  pcout("   Convergence value " + fmt("%.10e", rep.convergence_value));
+  pcout("   L1 solution norm " + fmt("%.10e", rep.sol_l1));
+  pcout("   L2 solution norm " + fmt("%.10e", rep.sol_l2));
+  pcout("   LInfinity solution norm " + fmt("%.10e", rep.sol_linf));
+  distribute_constraints(solution);  // :1016
+  return GMG_OK;
+}
+
+template <int dim>
+int LaplaceProblem<dim>::solve_again() {
+  CycleReport rep = reports.back();
+  const int rc = solve_on_device(rep);
+  reports.back().solve_seconds = rep.solve_seconds;
+  reports.back().cg_iterations = rep.cg_iterations;
+  reports.back().coarse_iterations = rep.coarse_iterations;
+  return rc;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::distribute_constraints(std::vector<double> &u) const {
+  for (size_t i = 0; i < constraint_of_dof.size(); ++i) {
+    const int32_t cl = constraint_of_dof[i];
+    if (cl < 0) continue;
+    const ConstraintLine &line = constraint_lines[(size_t)cl];
+    double v = line.inhomogeneity;
+    for (auto &e : line.entries) v += e.second * u[(size_t)e.first];
+    u[i] = v;
+  }
+}
+template <int dim>
+void LaplaceProblem<dim>::set_zero_constraints(std::vector<double> &u) const {
+  for (size_t i = 0; i < constraint_of_dof.size(); ++i)
+    if (constraint_of_dof[i] >= 0) u[i] = 0.0;
+}
+
+// ======================================================================== post-processing
+
+template <int dim>
+double LaplaceProblem<dim>::fe_value_at(const std::vector<double> &u, const double x[3]) const {
+  // GridTools::find_active_cell_around_point + FEValues::get_function_values (:1354-1363)
+  int c[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) {
+    c[d] = (int)std::floor((x[d] - triangulation.origin) / triangulation.h0);
+    c[d] = std::min(std::max(c[d], 0), triangulation.n0 - 1);
+  }
+  int level = 0;
+  int32_t ci = triangulation.find(0, c[0], c[1], c[2]);
+  while (!triangulation.active(level, ci)) {
+    const Cell &cell = triangulation.levels[(size_t)level][(size_t)ci];
+    const double h = triangulation.cell_size(level);
+    double x0[3];
+    triangulation.cell_origin(level, cell, x0);
+    int a = 0;
+    for (int d = 0; d < dim; ++d)
+      if (x[d] >= x0[d] + 0.5 * h) a |= 1 << d;
+    ci = cell.first_child + a;
+    ++level;
+  }
+  const Cell &cell = triangulation.levels[(size_t)level][(size_t)ci];
+  const double h = triangulation.cell_size(level);
+  double x0[3];
+  triangulation.cell_origin(level, cell, x0);
+  double t[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) t[d] = (x[d] - x0[d]) / h;
+  double v = 0;
+  for (int a = 0; a < (1 << dim); ++a) {
+    double w = 1;
+    for (int d = 0; d < dim; ++d) w *= ((a >> d) & 1) ? t[d] : 1.0 - t[d];
+    v += w * u[(size_t)dof_of_vertex.at(triangulation.vertex_key(level, cell, a))];
+  }
+  return v;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::postprocess_electrostatic_energy() {
+  // :1310-1420
+  CycleReport &rep = reports.back();
+  double analytical = 0, shortr = 0, fe = 0, self = 0;
+  for (unsigned i = 0; i < number_of_atoms; ++i)
+    for (unsigned j = i + 1; j < number_of_atoms; ++j) {
+      double r2 = 0;
+      for (int d = 0; d < 3; ++d) { const double t = atom_positions[3 * i + (size_t)d] - atom_positions[3 * j + (size_t)d]; r2 += t * t; }
+      const double r = std::sqrt(r2);
+      analytical += charges[i] * charges[j] / r;
+      shortr += charges[i] * (charges[j] * (std::erfc(r / par.r_c) / r));
+    }
+  for (unsigned i = 0; i < number_of_atoms; ++i) {
+    fe += 0.5 * charges[i] * fe_value_at(solution, &atom_positions[3 * i]);
+    self += charges[i] * charges[i] / (std::sqrt(M_PI) * par.r_c);
+  }
+  rep.has_energy = true;
+  rep.energy_analytical = analytical; rep.energy_short = shortr; rep.energy_fe_long = fe; rep.energy_self = self;
+  rep.energy_total = shortr + fe - self;
+  rep.energy_abs_error = std::fabs(std::fabs(analytical) - std::fabs(rep.energy_total));
+  pcout("\nTotal analytical electrostatic energy :   " + fmt("%.10e", analytical));
+  pcout("Short-ranged energy contribution :  " + fmt("%.10e", shortr));
+  pcout("FE solution long-ranged energy contribution :    " + fmt("%.10e", fe));
+  pcout("Self energy contribution : " + fmt("%.10e", self));
+  pcout("Total electrostatic energy with split in short- and long-ranged : " + fmt("%.10e", rep.energy_total));
+  pcout("Absolute Error between both energies :\t" + fmt("%.10e", rep.energy_abs_error) + "\n");
+  pcout("Relative Error in total electrostatic energy :\t" + fmt("%.10e", std::fabs((std::fabs(analytical) - std::fabs(rep.energy_total)) / analytical)));
+}
+
+// ======================================================================== adaptive loop
+
+template <int dim>
+int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
+  pcout("Cycle " + std::to_string(cycle) + ":");
+  if (cycle == 0) make_initial_grid();
+  else refine_grid(cycle);
+  reports.emplace_back();
+  CycleReport &rep = reports.back();
+  rep.cycle = (int)cycle;
+  rep.active_cells = triangulation.n_active_cells();
+  pcout("   Number of active cells:       " + std::to_string(rep.active_cells));
+  if (cycle == 0) {
+    setup_system(cycle);
+    initial_guess.assign(vertex_of_dof.size(), 0.0);
+  }
+  rep.dofs = (int64_t)vertex_of_dof.size();
+  std::string s = "   Number of degrees of freedom: " + std::to_string(rep.dofs) + " (by level: ";
+  for (int l = 0; l < triangulation.n_levels(); ++l) {
+    rep.dofs_by_level.push_back((int64_t)level_vertex_of_dof[(size_t)l].size());
+    s += std::to_string(rep.dofs_by_level.back()) + (l == triangulation.n_levels() - 1 ? ")" : ", ");
+  }
+  pcout(s);
+  assemble_system();
+  if (par.PreconditionerType == "GMG") assemble_multigrid();
+  build_transfer();
+  if (!on_device) return GMG_OK;
+  int rc = upload();
+  if (rc != GMG_OK) return rc;
+  rc = solve();
+  if (rc != GMG_OK) return rc;
+  estimate_error_and_mark_cells();
+  if (lammpsinput && number_of_atoms < 300) postprocess_electrostatic_energy();  // :1554-1555
+  return GMG_OK;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::run() {
+  pcout("Dimension:\t" + std::to_string(dim));
+  if (!lammpsinput && number_of_atoms == 0) read_lammps_input_file(par.LammpsInputFile);
+  for (unsigned int cycle = 0; cycle < par.number_of_adaptive_refinement_cycles; ++cycle) {
+    const int rc = run_cycle(cycle, true);
+    if (rc != GMG_OK) throw std::runtime_error("cycle " + std::to_string(cycle) + " failed: " + last_error);
+  }
+}
+
+}  // namespace step50
+
+#include "adaptive.inc"
+
+namespace step50 {
+template class LaplaceProblem<2>;
+template class LaplaceProblem<3>;
+}  // namespace step50

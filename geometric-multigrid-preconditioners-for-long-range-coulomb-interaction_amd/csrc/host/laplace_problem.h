@@ -1,0 +1,177 @@
+// laplace_problem.h -- host-side C++ mirror of the reference's Step50::LaplaceProblem<dim>
+// (/root/reference/include/step_50.h:111-202) for the GMG-CG hot path on MI355X.
+//
+// Same member names and meaning as the reference class; what the reference delegates to
+// deal.II / Trilinos / p4est is done here by forest.h (mesh), plain CSR containers (matrices)
+// and -- for everything on the hot path -- by the C-ABI of include/gmg_coulomb.h.  The outer
+// CG loop of solve() stays in this C++ (SolverCG below) and calls through that ABI.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "forest.h"
+#include "gmg_coulomb.h"
+
+namespace step50 {
+
+struct CSRMatrix {
+  int64_t n_rows = 0, n_cols = 0;
+  std::vector<int64_t> rowptr;
+  std::vector<int32_t> col;
+  std::vector<double> val;
+  int64_t nnz() const { return rowptr.empty() ? 0 : rowptr.back(); }
+  void add(int32_t r, int32_t c, double v);  // entry must be in the pattern
+  double l1_norm() const, linfty_norm() const, frobenius_norm() const;  // src/step-50.cc:950-952
+};
+
+// flat view of a deal.II .prm file (ParameterHandler keys of src/step-50.cc:13-95)
+class ParameterReader {
+ public:
+  void declare_parameters();                      // defaults, src/step-50.cc:13-95
+  void read_parameters(const std::string &file);  // src/step-50.cc:98-101
+  void parse_input_from_string(const std::string &text);
+  std::string get(const std::string &key) const;
+  double get_double(const std::string &key) const;
+  long get_integer(const std::string &key) const;
+  bool get_bool(const std::string &key) const;
+  void set(const std::string &key, const std::string &value) { values[key] = value; }
+
+ private:
+  std::map<std::string, std::string> values;
+};
+
+// the reference's 20 constructor arguments (include/step_50.h:115-118) + this build's additions
+struct Parameters {
+  unsigned int degree = 1;
+  std::string Problemtype = "Step16", PreconditionerType = "GMG", LammpsInputFile = "atom_8.data",
+              Boundary_conditions = "Inhomogeneous";
+  double domain_size_left = -1, domain_size_right = 1, mesh_size_h = 0.25;
+  unsigned int repetitions_for_vacuum = 1, number_of_global_refinement = 2, number_of_adaptive_refinement_cycles = 2;
+  double r_c = 0.5, nonzero_density_radius_parameter = 3;
+  bool flag_rhs_assembly = false, flag_analytical_solution = false, flag_rhs_field = false, flag_atoms_support = false,
+       flag_output_time = true;
+  unsigned int quadrature_degree_rhs = 1;
+  int dim = 2;
+  // additions (the smoother is a source edit in the reference, src/step-50.cc:969-970)
+  std::string smoother = "SSOR";  // Jacobi | SSOR | Chebyshev
+  double smoother_omega = 0.5;
+  int smoother_steps = 2, chebyshev_degree = 2;
+  bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
+  static Parameters from(const ParameterReader &prm);
+};
+
+struct CycleReport {  // the values the reference prints per cycle (src/step-50.cc:946-952, 1009-1014, ...)
+  int cycle = 0;
+  int64_t active_cells = 0, dofs = 0;
+  std::vector<int64_t> dofs_by_level;
+  double rhs_l1 = 0, rhs_l2 = 0, rhs_linf = 0, matrix_l1 = 0, matrix_linf = 0, matrix_frobenius = 0;
+  double starting_value = 0, convergence_value = 0, sol_l1 = 0, sol_l2 = 0, sol_linf = 0;
+  int cg_iterations = 0;
+  int64_t coarse_iterations = 0;
+  double refine_threshold = 0;
+  bool has_energy = false;
+  double energy_analytical = 0, energy_short = 0, energy_fe_long = 0, energy_self = 0, energy_total = 0, energy_abs_error = 0;
+  double solve_seconds = 0;  // first residual to convergence, excluding upload / build_matrices
+  int status = 0;
+};
+
+template <int dim>
+class LaplaceProblem {
+ public:
+  explicit LaplaceProblem(const Parameters &p);
+  ~LaplaceProblem();
+  void run();  // src/step-50.cc:1463-1573
+
+  // ---- protected in the reference (tests subclass it); public here for the C binding
+  void read_lammps_input_file(const std::string &filename);              // :181-258
+  void set_atoms(const std::vector<double> &q, const std::vector<double> &xyz);  // synthetic input of the same shape
+  void make_initial_grid();                                              // :1490-1528
+  void setup_system(unsigned int cycle);                                 // :646-732
+  void rhs_assembly_optimization();                                      // :260-306
+  void compute_charge_densities();                                       // :509-575
+  void compute_moments();                                                // :577-644
+  void assemble_system();                                                // :735-833
+  void assemble_multigrid();                                             // :835-933
+  void build_transfer();                                                 // mg_transfer.build_matrices, :957-958
+  int upload();                                                          // hand the operators over the C-ABI
+  int solve();                                                           // :938-1017
+  void estimate_error_and_mark_cells();                                  // :1020-1090
+  void refine_grid(unsigned int cycle);                                  // :1095-1121
+  void postprocess_electrostatic_energy();                               // :1310-1420
+  int run_cycle(unsigned int cycle, bool on_device = true);              // one iteration of the loop in run()
+  int solve_again();  // repeat the solve of the current cycle from the same initial guess (bench step)
+
+  // ---- data, named as in the reference where it exists (include/step_50.h:146-200)
+  Parameters par;
+  Forest<dim> triangulation;
+  std::vector<double> charges, atom_positions;  // positions: 3 * n
+  unsigned int number_of_atoms = 0;
+  bool lammpsinput = false;
+  CSRMatrix system_matrix;
+  std::vector<double> solution, system_rhs, initial_guess;
+  std::vector<CSRMatrix> mg_matrices, mg_interface_matrices, mg_prolongation;  // P_l: level l -> l+1
+  std::vector<std::vector<int32_t>> copy_global, copy_level;
+  double dipole_moment[3] = {0, 0, 0};
+  std::vector<CycleReport> reports;
+  std::string log;  // everything pcout would have printed
+  bool echo = false;
+  gmg_context *gmg = nullptr;
+  std::string last_error;
+
+  // DoF bookkeeping (Q1: DoFs = vertices)
+  struct ActiveCell { int32_t level, index; };
+  std::vector<ActiveCell> active_cells;
+  std::vector<std::vector<int32_t>> active_index_of_cell;  // [level][cell] -> position in active_cells or -1
+  std::unordered_map<uint64_t, int32_t> dof_of_vertex;
+  std::vector<uint64_t> vertex_of_dof;
+  std::vector<std::unordered_map<uint64_t, int32_t>> level_dof_of_vertex;
+  std::vector<std::vector<uint64_t>> level_vertex_of_dof;
+  // constraints (hanging nodes + Dirichlet), resolved: masters are unconstrained DoFs
+  struct ConstraintLine { std::vector<std::pair<int32_t, double>> entries; double inhomogeneity = 0; bool hanging = false; };
+  std::vector<int32_t> constraint_of_dof;  // -1 = unconstrained
+  std::vector<ConstraintLine> constraint_lines;
+  std::vector<std::vector<char>> level_boundary, level_refinement_edge;  // MGConstrainedDoFs
+  std::vector<std::vector<double>> density_values_for_each_cell;         // [active cell][q]
+  std::vector<float> error_per_cell;
+  std::vector<std::vector<char>> refine_flags;
+
+  void pcout(const std::string &s);
+  void distribute_dofs();
+  void make_constraints();
+  void cell_dofs(const ActiveCell &c, int32_t *out) const;
+  void level_cell_dofs(int level, int32_t cell, int32_t *out) const;
+  double boundary_value(const double x[3]) const;
+  double rhs_function(const double x[3]) const;
+  double coefficient(const double x[3]) const;
+  void atoms_of_root_cell(const int rc[3], std::vector<int32_t> &out) const;
+  double fe_value_at(const std::vector<double> &u, const double x[3]) const;
+  void distribute_constraints(std::vector<double> &u) const;  // constraints.distribute, :1016
+  void set_zero_constraints(std::vector<double> &u) const;    // constraints.set_zero, :1119
+
+ private:
+  struct AtomBins;
+  std::unique_ptr<AtomBins> bins;
+  double *d_solution = nullptr, *d_rhs = nullptr;
+  int64_t d_n = 0;
+  int solve_on_device(CycleReport &rep);
+};
+
+// deal.II SolverCG<vector_t> restated on top of the C-ABI: every vector is a device pointer,
+// every operation one ABI call (reference: src/step-50.cc:943, 991-992; operation order as in
+// oracle/gmg_oracle.c:cg_solve).
+struct SolverControl {
+  int max_steps;
+  double tolerance;
+  double initial_value = 0, last_value = 0;
+  int last_step = 0;
+};
+int SolverCG_solve(gmg_context *ctx, SolverControl &control, int64_t n, int64_t n_vec, double *x, const double *b,
+                   const std::string &preconditioner);
+
+std::vector<double> nacl_lattice(int n_cells, std::vector<double> &charges);  // the reference's atom/*.data generator
+
+}  // namespace step50

@@ -1,0 +1,196 @@
+"""ctypes binding of the host-side C++ (csrc/host/libstep50host.so): the mirror of the
+reference's LaplaceProblem<dim> and main.cc.  Drives mesh/assembly on the CPU and the solve
+on the MI355X through the C-ABI.  No CPU fallback for the solve."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class Report(C.Structure):
+    _fields_ = [("cycle", C.c_int32), ("cg_iterations", C.c_int32), ("status", C.c_int32), ("has_energy", C.c_int32),
+                ("n_levels", C.c_int32), ("pad", C.c_int32),
+                ("active_cells", C.c_int64), ("dofs", C.c_int64), ("coarse_iterations", C.c_int64),
+                ("dofs_by_level", C.c_int64 * 16),
+                ("rhs_l1", C.c_double), ("rhs_l2", C.c_double), ("rhs_linf", C.c_double),
+                ("matrix_l1", C.c_double), ("matrix_linf", C.c_double), ("matrix_frobenius", C.c_double),
+                ("starting_value", C.c_double), ("convergence_value", C.c_double),
+                ("sol_l1", C.c_double), ("sol_l2", C.c_double), ("sol_linf", C.c_double), ("refine_threshold", C.c_double),
+                ("energy_analytical", C.c_double), ("energy_short", C.c_double), ("energy_fe_long", C.c_double),
+                ("energy_self", C.c_double), ("energy_total", C.c_double), ("energy_abs_error", C.c_double),
+                ("solve_seconds", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("dofs_by_level", "pad")}
+        d["dofs_by_level"] = [int(self.dofs_by_level[i]) for i in range(self.n_levels)]
+        return d
+
+
+def load(build_if_missing: bool = False):
+    global _lib
+    if _lib is None:
+        if build_if_missing:
+            _build.build_all()
+        if not os.path.exists(_build.LIB_HOST):
+            raise FileNotFoundError(f"{_build.LIB_HOST} missing: run __graft_entry__.build()")
+        _lib = C.CDLL(_build.LIB_HOST)
+        _lib.step50_create.restype = C.c_void_p
+        _lib.step50_last_error.restype = C.c_char_p
+        _lib.step50_log.restype = C.c_char_p
+        _lib.step50_gmg_context.restype = C.c_void_p
+        for f in ("step50_n_atoms", "step50_copy_indices_size", "step50_n_dofs"):
+            getattr(_lib, f).restype = C.c_int64
+    return _lib
+
+
+def prm_text(**kw) -> str:
+    """A .prm file body with the reference's keys (src/step-50.cc:13-95)."""
+    keymap = {
+        "global_refinement": ("Geometry", "Number of global refinement"),
+        "left": ("Geometry", "Domain limit left"), "right": ("Geometry", "Domain limit right"),
+        "mesh_size": ("Geometry", "Mesh size"), "vacuum": ("Geometry", "Vacuum repetitions"),
+        "problem": ("Problem Selection", "Problem"), "dim": ("Problem Selection", "Dimension"),
+        "bc": ("Problem Selection", "Boundary conditions selection"),
+        "cycles": ("Misc", "Number of Adaptive Refinement"), "r_c": ("Misc", "smoothing length"),
+        "cutoff": ("Misc", "Nonzero Density radius parameter around each charge"),
+        "rhs_optimization": ("Misc", "Flag for RHS evaluation optimization"),
+        "quad_rhs": ("Misc", "Quadrature points for RHS function"),
+        "preconditioner": ("Solver input data", "Preconditioner"),
+        "lammps": ("Lammps data", "Lammps input file"),
+        "smoother": ("Solver input data", "Smoother"), "omega": ("Solver input data", "Smoother damping"),
+        "steps": ("Solver input data", "Smoother steps"), "cheb_degree": ("Solver input data", "Chebyshev degree"),
+        "device_cg": ("Solver input data", "Device resident outer CG"),
+    }
+    sections = {}
+    for k, v in kw.items():
+        sec, key = keymap[k]
+        if isinstance(v, bool):
+            v = "true" if v else "false"
+        sections.setdefault(sec, []).append(f"  set {key} = {v}")
+    out = ["set Polynomial degree = 1"]
+    for sec, lines in sections.items():
+        out += [f"subsection {sec}"] + lines + ["end"]
+    return "\n".join(out) + "\n"
+
+
+class Problem:
+    def __init__(self, prm: str):
+        self.L = load()
+        err = C.create_string_buffer(512)
+        self.h = C.c_void_p(self.L.step50_create(prm.encode(), err, 512))
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def close(self):
+        if self.h:
+            self.L.step50_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed (rc={rc}): {self.L.step50_last_error(self.h).decode()}")
+
+    def read_lammps(self, path):
+        self._chk(self.L.step50_read_lammps(self.h, path.encode()), "read_lammps_input_file")
+
+    def set_atoms(self, q, xyz):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        x = np.ascontiguousarray(xyz, dtype=np.float64)
+        self._chk(self.L.step50_set_atoms(self.h, C.c_int64(len(q)), q.ctypes.data_as(C.POINTER(C.c_double)),
+                                          x.ctypes.data_as(C.POINTER(C.c_double))), "set_atoms")
+
+    def set_nacl_atoms(self, n_cells):
+        self._chk(self.L.step50_set_nacl_atoms(self.h, C.c_int(n_cells)), "set_nacl_atoms")
+
+    def atoms(self):
+        n = self.L.step50_n_atoms(self.h)
+        q, x = np.empty(n), np.empty((n, 3))
+        self.L.step50_get_atoms(self.h, q.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)))
+        return q, x
+
+    def run_cycle(self, cycle: int, on_device: bool = True):
+        self._chk(self.L.step50_run_cycle(self.h, C.c_int(cycle), C.c_int(1 if on_device else 0)), f"cycle {cycle}")
+        return self.report(-1)
+
+    def solve_again(self):
+        self._chk(self.L.step50_solve_again(self.h), "solve")
+        return self.report(-1)
+
+    def report(self, i=-1) -> dict:
+        r = Report()
+        self._chk(self.L.step50_get_report(self.h, C.c_int(i), C.byref(r)), "get_report")
+        return r.as_dict()
+
+    def log(self) -> str:
+        return self.L.step50_log(self.h).decode()
+
+    def n_levels(self):
+        return int(self.L.step50_n_levels(self.h))
+
+    def n_dofs(self):
+        return int(self.L.step50_n_dofs(self.h))
+
+    def matrix(self, kind, level=0):
+        """kind: 'system' | 'level' | 'edge' | 'prolongation' -> namespace(n_rows, n_cols, rowptr, col, val, nnz)"""
+        k = {"system": 0, "level": 1, "edge": 2, "prolongation": 3}[kind]
+        nr, nc, nz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.step50_matrix_shape(self.h, C.c_int(k), C.c_int(level), C.byref(nr), C.byref(nc), C.byref(nz)), "matrix")
+        rp = np.zeros(nr.value + 1, dtype=np.int64)
+        col = np.zeros(max(nz.value, 1), dtype=np.int32)
+        val = np.zeros(max(nz.value, 1), dtype=np.float64)
+        if nr.value > 0:
+            self.L.step50_matrix_copy(self.h, C.c_int(k), C.c_int(level), rp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      col.ctypes.data_as(C.POINTER(C.c_int32)), val.ctypes.data_as(C.POINTER(C.c_double)))
+        return SimpleNamespace(n_rows=nr.value, n_cols=nc.value, rowptr=rp, col=col[:nz.value], val=val[:nz.value], nnz=nz.value)
+
+    def copy_indices(self, level):
+        n = self.L.step50_copy_indices_size(self.h, C.c_int(level))
+        g, l = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+        if n:
+            self.L.step50_copy_indices(self.h, C.c_int(level), g.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       l.ctypes.data_as(C.POINTER(C.c_int32)))
+        return g[:n], l[:n]
+
+    def vector(self, which):
+        w = {"rhs": 0, "solution": 1, "initial_guess": 2}[which]
+        out = np.zeros(self.n_dofs())
+        self.L.step50_get_vector(self.h, C.c_int(w), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def dof_coordinates(self):
+        out = np.zeros((self.n_dofs(), 3))
+        self.L.step50_dof_coordinates(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def constrained_mask(self):
+        out = np.zeros(self.n_dofs(), dtype=np.int8)
+        self.L.step50_constrained_mask(self.h, out.ctypes.data_as(C.POINTER(C.c_int8)))
+        return out.astype(bool)
+
+    def hierarchy(self):
+        """What LaplaceProblem::solve consumes, as plain arrays (for the oracle in tests)."""
+        L = self.n_levels()
+        return SimpleNamespace(
+            system_matrix=self.matrix("system"), system_rhs=self.vector("rhs"),
+            level_matrices=[self.matrix("level", l) for l in range(L)],
+            edge_matrices=[self.matrix("edge", l) for l in range(L)],
+            prolongations=[self.matrix("prolongation", l) for l in range(L - 1)],
+            copy_global=[self.copy_indices(l)[0] for l in range(L)],
+            copy_level=[self.copy_indices(l)[1] for l in range(L)],
+            constrained=self.constrained_mask())
+
+    def gmg_context(self):
+        return C.c_void_p(self.L.step50_gmg_context(self.h))

@@ -1,0 +1,61 @@
+"""GPU tests of the whole drop-in path: host C++ (LaplaceProblem mirror) -> C-ABI -> HIP,
+against the reference's golden logs and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+from gpu_util import pkg
+from oracle import gmg_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(**kw):
+    S = pkg().step50
+    return S.Problem(S.prm_text(**kw))
+
+
+def test_cycle0_two_atoms_matches_reference_log(golden, golden_dir):
+    """tests/gaussian-charges.mpirun=1.output:8-29, all printed quantities incl. energies."""
+    g = golden["tests/gaussian-charges.mpirun=1"]["runs"][0]["cycles"][0]
+    p = _problem(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact", cycles=1,
+                 r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0, smoother="SSOR")
+    p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
+    r = p.run_cycle(0)
+    assert r["cg_iterations"] == g["cg_iterations"] == 1 and r["coarse_iterations"] == 112
+    for k in ("rhs_l1", "rhs_l2", "rhs_linf", "matrix_l1", "matrix_linf", "matrix_frobenius", "sol_l1", "sol_l2", "sol_linf"):
+        assert rel_close(r[k], g[k], 11), k
+    assert abs(r["starting_value"] - g["starting_value"]) < 0.6e-10
+    assert abs(r["convergence_value"] - g["convergence_value"]) < 1e-5 * g["convergence_value"]
+    for k in ("energy_analytical", "energy_short", "energy_fe_long", "energy_self"):
+        assert rel_close(r[k], g[k], 11), k
+    assert rel_close(r["energy_total"], g["energy_total_split"], 11)
+    assert rel_close(r["energy_abs_error"], g["energy_abs_error"], 10)
+    log = p.log()
+    assert "   CG converged in 1 iterations." in log and "   L1 solution norm 1.2024932115e+03" in log
+
+
+@pytest.mark.parametrize("device_cg", [False, True])
+def test_five_level_jacobi_host_cg_and_device_cg(golden, device_cg):
+    g = golden["tests_3D/step-16.mpirun=1"]["runs"][0]["cycles"][0]
+    p = _problem(left=0, right=1, problem="Step16", dim=3, bc="Homogeneous", cycles=1, global_refinement=4,
+                 smoother="Jacobi", device_cg=device_cg)
+    r = p.run_cycle(0)
+    assert r["cg_iterations"] == g["cg_iterations"] == 8
+    for k in ("sol_l1", "sol_l2", "sol_linf"):
+        assert rel_close(r[k], g[k], 6)
+    r2 = p.solve_again()
+    assert r2["cg_iterations"] == 8
+
+
+def test_solution_matches_oracle_all_smoothers():
+    for sm, kind in (("Jacobi", go.JACOBI), ("Chebyshev", go.CHEBYSHEV), ("SSOR", go.SSOR)):
+        p = _problem(left=0, right=1, problem="Step16", dim=3, bc="Homogeneous", cycles=1, global_refinement=4, smoother=sm)
+        r = p.run_cycle(0)
+        h = p.hierarchy()
+        ref = go.OracleMG(h, smoother=kind).solve(h.system_rhs)
+        assert r["cg_iterations"] == ref["iterations"], sm
+        x = p.vector("solution")
+        assert np.abs(x - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max(), sm

@@ -1,0 +1,130 @@
+"""Host-side C++ (csrc/host: mirror of the reference's LaplaceProblem) against the numpy oracle
+generator and the golden logs -- CPU only.  The host code produces the inputs of the hot path;
+these tests show the two independent producers agree entry by entry."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_close
+from gpu_util import pkg
+from oracle import gmg_oracle as go
+from oracle import step50_oracle as so
+
+
+def S():
+    pkg().build.build_all()
+    return pkg().step50
+
+
+def _perm_compare(hm, om, perm, tol=1e-13):
+    """host matrix (its DoF order) == oracle matrix (lexicographic order) under the DoF permutation."""
+    assert hm.n_rows == om.n_rows and hm.nnz == om.nnz
+    n = om.n_cols
+    rows = np.repeat(np.arange(hm.n_rows), np.diff(hm.rowptr))
+    hk = perm[rows].astype(np.int64) * n + perm[hm.col]
+    o = np.argsort(hk)
+    rows_o = np.repeat(np.arange(om.n_rows), np.diff(om.rowptr))
+    ok = rows_o.astype(np.int64) * n + om.col
+    oo = np.argsort(ok)
+    assert np.array_equal(hk[o], ok[oo])
+    assert np.abs(hm.val[o] - om.val[oo]).max() <= tol * np.abs(om.val).max()
+
+
+def _lex_index(coords, lat):
+    idx = np.rint((coords[:, :lat.dim] - lat.origin) / lat.h).astype(np.int64)
+    out = idx[:, 0].copy()
+    for d in range(1, lat.dim):
+        out += idx[:, d] * lat.nv ** d
+    return out
+
+
+def test_parameter_reader_rejects_unknown_keys():
+    with pytest.raises(RuntimeError):
+        S().Problem("subsection Geometry\n set No such key = 1\nend\n")
+
+
+def test_nacl_generator_matches_reference_atom_files(golden_dir):
+    """The bench's synthetic atoms are the reference's atom/*.data files regenerated."""
+    Sm = S()
+    for n, name in [(1, "atom_n1_8.data"), (3, "atom_n3_216.data")]:
+        p = Sm.Problem(Sm.prm_text(problem="GaussianCharges", dim=3))
+        p.set_nacl_atoms(n)
+        q, x = p.atoms()
+        qr, xr = so.read_lammps(os.path.join(golden_dir, name))
+        assert np.array_equal(q, qr) and np.array_equal(x, xr)
+        p2 = Sm.Problem(Sm.prm_text(problem="GaussianCharges", dim=3))
+        p2.read_lammps(os.path.join(golden_dir, name))
+        q2, x2 = p2.atoms()
+        assert np.array_equal(q2, qr) and np.array_equal(x2, xr)
+    ref = "/root/reference/atom/atom_n5_1000.data"
+    if os.path.exists(ref):
+        p = Sm.Problem(Sm.prm_text(problem="GaussianCharges", dim=3))
+        p.set_nacl_atoms(5)
+        q, x = p.atoms()
+        qr, xr = so.read_lammps(ref)
+        assert np.array_equal(q, qr) and np.array_equal(x, xr)
+
+
+def test_host_assembly_equals_oracle_generator_8_atoms(golden_dir):
+    Sm = S()
+    p = Sm.Problem(Sm.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
+                               bc="Inhomogeneous", cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1,
+                               global_refinement=0))
+    p.read_lammps(os.path.join(golden_dir, "atom_n1_8.data"))
+    rep = p.run_cycle(0, on_device=False)
+    q, x = p.atoms()
+    oh = so.build_gaussian_cycle0(q, x, left=0, right=1, h=0.25, vacuum=10, r_c=0.5, cutoff_param=3.5, n_q_rhs=1,
+                                  bc="Inhomogeneous")
+    assert rep["dofs_by_level"] == [91125] and rep["active_cells"] == 85184
+    perm = _lex_index(p.dof_coordinates(), oh.lattice)
+    assert np.array_equal(np.sort(perm), np.arange(91125))
+    hh = p.hierarchy()
+    b = np.zeros(91125)
+    b[perm] = hh.system_rhs
+    assert np.abs(b - oh.system_rhs).max() <= 1e-13 * np.abs(oh.system_rhs).max()
+    assert hh.system_matrix.nnz == (3 * 45 - 2) ** 3
+    _perm_compare(hh.system_matrix, oh.system_matrix, perm)
+    _perm_compare(hh.level_matrices[0], oh.level_matrices[0], perm)
+    cm = np.zeros(91125, dtype=bool)
+    cm[perm] = hh.constrained
+    assert np.array_equal(cm, oh.constrained)
+
+
+@pytest.mark.parametrize("dim,key", [(2, "tests_2D/step-16.mpirun=1"), (3, "tests_3D/step-16.mpirun=1")])
+def test_host_five_level_hierarchy_reproduces_golden(golden, dim, key):
+    """Host-produced operators + oracle solver == the reference's printed cycle 0."""
+    g = golden[key]["runs"][0]["cycles"][0]
+    Sm = S()
+    p = Sm.Problem(Sm.prm_text(left=0, right=1, problem="Step16", dim=dim, bc="Homogeneous", cycles=1,
+                               global_refinement=4, smoother="Jacobi"))
+    rep = p.run_cycle(0, on_device=False)
+    assert rep["dofs_by_level"] == g["dofs_by_level"] and rep["active_cells"] == g["active_cells"]
+    h = p.hierarchy()
+    r = go.OracleMG(h, smoother=go.JACOBI).solve(h.system_rhs)
+    x = r["x"]
+    assert r["iterations"] == g["cg_iterations"]
+    assert rel_close(float(np.abs(x).sum()), g["sol_l1"], 6)
+    assert rel_close(float(np.sqrt(x @ x)), g["sol_l2"], 6)
+    assert rel_close(float(np.abs(x).max()), g["sol_linf"], 6)
+    for P in h.prolongations:  # rows sum to 1 except where coarse boundary columns were zeroed
+        s = np.zeros(P.n_rows)
+        np.add.at(s, np.repeat(np.arange(P.n_rows), np.diff(P.rowptr)), P.val)
+        assert s.max() <= 1.0 + 1e-15 and s.min() >= 0.0
+
+
+def test_host_two_atom_exact_bc_golden(golden, golden_dir):
+    """tests/gaussian-charges.mpirun=1.output:8-15: rhs and matrix norms from the host assembly."""
+    g = golden["tests/gaussian-charges.mpirun=1"]["runs"][0]["cycles"][0]
+    Sm = S()
+    p = Sm.Problem(Sm.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
+                               cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0))
+    p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
+    p.run_cycle(0, on_device=False)
+    h = p.hierarchy()
+    b = h.system_rhs
+    assert rel_close(float(np.abs(b).sum()), g["rhs_l1"], 11)
+    assert rel_close(float(np.sqrt(b @ b)), g["rhs_l2"], 11)
+    assert rel_close(float(np.abs(b).max()), g["rhs_linf"], 11)
+    A = h.system_matrix
+    assert rel_close(float(np.sqrt((A.val ** 2).sum())), g["matrix_frobenius"], 11)
