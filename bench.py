@@ -71,10 +71,16 @@ def main():
         torch.cuda.synchronize()
 
     os.environ["STEP50_DEVICE"] = str(local_rank)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, world))))
     p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
                              quad_rhs=1, global_refinement=0, smoother=args.smoother))
     p.set_nacl_atoms(w["nacl"])
+    if world > 1:
+        # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
+        box = [pkg.capi.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        p.set_communicator(rank, world, box[0])
     t_setup = time.time()
     rep = None
     for cycle in range(args.cycles):
@@ -101,7 +107,7 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     dofs, its = rep["dofs"], rep_t["cg_iterations"]
-    value = dofs * its * world / (dt / args.steps)
+    value = dofs * its / (dt / args.steps)  # the ranks solve ONE problem together (strong scaling)
 
     n0, nnz0 = st.spmv0_rows, st.spmv0_nnz
     roof = None

@@ -27,7 +27,8 @@ SYMBOLS = [
     "gmg_vec_add", "gmg_vec_sadd", "gmg_vec_dot", "gmg_vec_norms", "gmg_vec_all_zero",
     "gmg_spmv", "gmg_precondition", "gmg_precondition_jacobi", "gmg_coarse_solve", "gmg_smoother_step",
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
-    "gmg_comm_unique_id", "gmg_comm_init", "gmg_set_halo_plan",
+    "gmg_comm_unique_id", "gmg_comm_init", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
+    "gmg_vec_allgather",
     "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning",
 ]
 
@@ -257,6 +258,12 @@ class Context:
     def comm_init(self, rank, n_ranks, uid: bytes):
         buf = C.create_string_buffer(uid, UNIQUE_ID_BYTES)
         self._chk(self.L.gmg_comm_init(self.h, C.c_int(rank), C.c_int(n_ranks), buf))
+
+    def set_global_sizes(self, n_system, n_level0):
+        self._chk(self.L.gmg_set_global_sizes(self.h, C.c_int64(n_system), C.c_int64(n_level0)))
+
+    def allgather(self, n_global, dst_full, src_local):
+        self._chk(self.L.gmg_vec_allgather(self.h, C.c_int64(n_global), dst_full.ptr, src_local.ptr))
 
     def set_halo_plan(self, which, neighbor_rank, send_count, send_idx, recv_count):
         nr = np.ascontiguousarray(neighbor_rank, dtype=np.int32)

@@ -46,6 +46,9 @@ struct Level {
   int64_t n_copy = 0;
   int32_t *copy_g = nullptr, *copy_l = nullptr;
   double *sol = nullptr, *def = nullptr, *t = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+  // distributed runs keep levels >= 1 replicated and level 0 row-partitioned: the V-cycle sees
+  // level 0 through these full-length replicas (aliases of sol/def on a single GPU)
+  double *sol_full = nullptr, *def_full = nullptr;
   double *invd = nullptr;
   double cheb_lmax = 0.0;
   SgsPlan sgs;
@@ -87,6 +90,9 @@ struct gmg_context {
   int ev_used = 0, ev2_used = 0;
   gmg_stats stats{};
   Comm comm;
+  bool dist = false;             // communicator initialised: level 0 + system rows are partitioned
+  int64_t sys_global = 0, l0_global = 0;
+  double *sys_full_a = nullptr, *sys_full_b = nullptr;  // replicated src / dst of the V-cycle
   std::string err;
 };
 
@@ -432,15 +438,48 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   return GMG_OK;
 }
 
+
+// ---- canonical row partition of distributed runs: equal chunks, rank r owns
+// [r*chunk, min((r+1)*chunk, n)); chosen so that ncclAllGather can rebuild a replica in place.
+inline int64_t part_chunk(int64_t n, int n_ranks) { return (n + n_ranks - 1) / n_ranks; }
+inline void part_range(int64_t n, int rank, int n_ranks, int64_t *b, int64_t *e) {
+  const int64_t c = part_chunk(n, n_ranks);
+  *b = std::min<int64_t>(n, (int64_t)rank * c);
+  *e = std::min<int64_t>(n, (int64_t)(rank + 1) * c);
+}
+
+// full[0 .. n_global) <- concatenation of every rank's owned slice (local[0 .. n_owned))
+int allgather_full(gmg_context *ctx, double *full, const double *local, int64_t n_global) {
+  const int64_t c = part_chunk(n_global, ctx->comm.n_ranks);
+  int64_t b, e;
+  part_range(n_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
+  // stage the owned slice at its place; the padded tail of the last chunks is never read
+  if (e > b) HIPC(hipMemcpyAsync(full + b, local, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ncclAllGather(full + (int64_t)ctx->comm.rank * c, full, (size_t)c, ncclDouble, ctx->comm.comm, ctx->stream) != ncclSuccess)
+    return fail(ctx, GMG_ERR_COMM, "all-gather failed");
+  return GMG_OK;
+}
+
+// MGCoarseGridBase::operator() as the V-cycle sees it: replicated defect in, replicated solution out
+int coarse_level_solve(gmg_context *ctx) {
+  Level &L0 = ctx->lv[0];
+  if (!ctx->dist) return coarse_solve(ctx, L0.sol, L0.def, nullptr, nullptr);
+  int64_t b, e;
+  part_range(ctx->l0_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
+  if (e > b) HIPC(hipMemcpyAsync(L0.def, L0.def_full + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
+  CHK(coarse_solve(ctx, L0.sol, L0.def, nullptr, nullptr));
+  return allgather_full(ctx, L0.sol_full, L0.sol, ctx->l0_global);
+}
+
 // ---- V-cycle (A5, A6, A8) -----------------------------------------------------------------
 
 int level_v_step(gmg_context *ctx, int l) {
   Level &L = ctx->lv[(size_t)l];
-  if (l == 0) return coarse_solve(ctx, L.sol, L.def, nullptr, nullptr);
+  if (l == 0) return coarse_level_solve(ctx);
   Level &C = ctx->lv[(size_t)l - 1];
+  double *c_def = (l == 1) ? C.def_full : C.def, *c_sol = (l == 1) ? C.sol_full : C.sol;
   const int g = grid_for(L.n);
   CHK(smooth_level(ctx, l, &L.sol, L.def, true, &L.w1));  // pre_smooth->apply (Jacobi may swap sol <-> w1)
-  CHK(import_ghosts(ctx, L.A, L.sol));
   if (L.has_I) {
     CHK(spmv(ctx, L.A, kStore, L.sol, L.t));                 // t = A u
     CHK(spmv(ctx, L.I, kStore, L.sol, L.t, L.t));            // edge_out->vmult_add
@@ -448,13 +487,10 @@ int level_v_step(gmg_context *ctx, int l) {
   } else {
     CHK(spmv(ctx, L.A, kResid, L.sol, L.t, nullptr, L.def));  // t = defect - A u
   }
-  CHK(import_ghosts(ctx, C.Pt, L.t));
-  CHK(spmv(ctx, C.Pt, kStore, L.t, C.def, C.def));            // restrict_and_add
+  CHK(spmv(ctx, C.Pt, kStore, L.t, c_def, c_def));            // restrict_and_add
   CHK(level_v_step(ctx, l - 1));
-  CHK(import_ghosts(ctx, C.P, C.sol));
-  CHK(spmv(ctx, C.P, kAddTo, C.sol, L.sol, nullptr, L.sol));  // u += P u_c
+  CHK(spmv(ctx, C.P, kAddTo, c_sol, L.sol, nullptr, L.sol));  // u += P u_c
   if (L.has_I) {
-    CHK(import_ghosts(ctx, L.It, L.sol));
     CHK(spmv(ctx, L.It, kResid, L.sol, L.def, nullptr, L.def));  // defect -= I^T u
   }
   CHK(smooth_level(ctx, l, &L.sol, L.def, false, &L.w1));     // post_smooth->smooth
@@ -463,22 +499,39 @@ int level_v_step(gmg_context *ctx, int l) {
 
 int vcycle(gmg_context *ctx, double *dst, const double *src) {
   if (!ctx->S.valid) return fail(ctx, GMG_ERR_INVALID, "system matrix not set");
+  const double *src_v = src;
+  double *dst_v = dst;
+  int64_t n_sys = ctx->S.n_rows;
+  if (ctx->dist) {  // PreconditionMG sees replicas of the outer vectors; only level 0 stays partitioned
+    CHK(allgather_full(ctx, ctx->sys_full_a, src, ctx->sys_global));
+    src_v = ctx->sys_full_a;
+    dst_v = ctx->sys_full_b;
+    n_sys = ctx->sys_global;
+  }
   for (int l = 0; l < ctx->n_levels; ++l) {  // copy_to_mg
     Level &L = ctx->lv[(size_t)l];
     if (!L.A.valid) return fail(ctx, GMG_ERR_INVALID, "level matrix not set");
-    HIPC(hipMemsetAsync(L.def, 0, sizeof(double) * (size_t)L.n_vec, ctx->stream));
-    HIPC(hipMemsetAsync(L.sol, 0, sizeof(double) * (size_t)L.n_vec, ctx->stream));
+    double *def = (l == 0) ? L.def_full : L.def;
+    const int64_t nl = (l == 0 && ctx->dist) ? ctx->l0_global : L.n_vec;
+    HIPC(hipMemsetAsync(def, 0, sizeof(double) * (size_t)nl, ctx->stream));
+    if (l > 0) HIPC(hipMemsetAsync(L.sol, 0, sizeof(double) * (size_t)L.n_vec, ctx->stream));
     if (L.n_copy)
-      hipLaunchKernelGGL(gather_scatter_kernel, dim3(grid_for(L.n_copy)), dim3(kThreads), 0, ctx->stream, L.def,
-                         (const int32_t *)L.copy_l, src, (const int32_t *)L.copy_g, L.n_copy);
+      hipLaunchKernelGGL(gather_scatter_kernel, dim3(grid_for(L.n_copy)), dim3(kThreads), 0, ctx->stream, def,
+                         (const int32_t *)L.copy_l, src_v, (const int32_t *)L.copy_g, L.n_copy);
   }
   CHK(level_v_step(ctx, ctx->n_levels - 1));
-  HIPC(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)ctx->S.n_rows, ctx->stream));  // copy_from_mg: dst = 0
+  HIPC(hipMemsetAsync(dst_v, 0, sizeof(double) * (size_t)n_sys, ctx->stream));  // copy_from_mg: dst = 0
   for (int l = 0; l < ctx->n_levels; ++l) {
     Level &L = ctx->lv[(size_t)l];
+    const double *sol = (l == 0) ? L.sol_full : L.sol;
     if (L.n_copy)
-      hipLaunchKernelGGL(gather_scatter_kernel, dim3(grid_for(L.n_copy)), dim3(kThreads), 0, ctx->stream, dst,
-                         (const int32_t *)L.copy_g, (const double *)L.sol, (const int32_t *)L.copy_l, L.n_copy);
+      hipLaunchKernelGGL(gather_scatter_kernel, dim3(grid_for(L.n_copy)), dim3(kThreads), 0, ctx->stream, dst_v,
+                         (const int32_t *)L.copy_g, sol, (const int32_t *)L.copy_l, L.n_copy);
+  }
+  if (ctx->dist) {
+    int64_t b, e;
+    part_range(ctx->sys_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
+    if (e > b) HIPC(hipMemcpyAsync(dst, dst_v + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
   }
   ctx->stats.vcycles++;
   return GMG_OK;
@@ -584,6 +637,8 @@ int gmg_destroy(gmg_context *ctx) {
   comm_destroy(ctx->comm);
   for (auto &L : ctx->lv) {
     free_csr(L.A); free_csr(L.I); free_csr(L.It); free_csr(L.P); free_csr(L.Pt);
+    if (L.sol_full && L.sol_full != L.sol) (void)hipFree(L.sol_full);
+    if (L.def_full && L.def_full != L.def) (void)hipFree(L.def_full);
     for (double *p : {L.sol, L.def, L.t, L.w1, L.w2, L.w3, L.invd})
       if (p) (void)hipFree(p);
     if (L.copy_g) (void)hipFree(L.copy_g);
@@ -592,7 +647,7 @@ int gmg_destroy(gmg_context *ctx) {
     if (L.sgs.stage_rows) (void)hipFree(L.sgs.stage_rows);
   }
   free_csr(ctx->S);
-  for (double *p : {ctx->S_invd, ctx->S_tmp, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, ctx->cg_h, ctx->part_a, ctx->part_b, ctx->scal_dev})
+  for (double *p : {ctx->sys_full_a, ctx->sys_full_b, ctx->S_invd, ctx->S_tmp, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, ctx->cg_h, ctx->part_a, ctx->part_b, ctx->scal_dev})
     if (p) (void)hipFree(p);
   if (ctx->st) (void)hipFree(ctx->st);
   if (ctx->st_host) (void)hipHostFree(ctx->st_host);
@@ -619,6 +674,14 @@ int gmg_set_system_matrix(gmg_context *ctx, int64_t n_rows, int64_t n_cols, cons
   CHK(upload_csr(ctx, ctx->S, n_rows, n_cols, rowptr, col, val));
   CHK(setup_diag(ctx, n_rows, rowptr, col, val, &ctx->S_invd, nullptr));
   CHK(alloc_vec(ctx, &ctx->S_tmp, n_cols));
+  if (ctx->dist) {
+    const int64_t padded = part_chunk(ctx->sys_global, ctx->comm.n_ranks) * ctx->comm.n_ranks;
+    CHK(alloc_vec(ctx, &ctx->sys_full_a, padded));
+    CHK(alloc_vec(ctx, &ctx->sys_full_b, padded));
+    int64_t b, e;
+    part_range(ctx->sys_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
+    if (e - b != n_rows) return fail(ctx, GMG_ERR_INVALID, "system matrix rows do not match the canonical partition");
+  }
   return GMG_OK;
 }
 
@@ -634,6 +697,17 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
   for (double **p : {&L.sol, &L.def, &L.t, &L.w1, &L.w2, &L.w3}) CHK(alloc_vec(ctx, p, n_cols));
   if (level > 0) CHK(setup_sgs(ctx, L, n_rows, rowptr, col));
   if (level == 0) {
+    if (ctx->dist) {
+      const int64_t padded = part_chunk(ctx->l0_global, ctx->comm.n_ranks) * ctx->comm.n_ranks;
+      if (L.sol_full && L.sol_full != L.sol) (void)hipFree(L.sol_full);
+      if (L.def_full && L.def_full != L.def) (void)hipFree(L.def_full);
+      L.sol_full = L.def_full = nullptr;
+      CHK(alloc_vec(ctx, &L.sol_full, padded));
+      CHK(alloc_vec(ctx, &L.def_full, padded));
+    } else {
+      L.sol_full = L.sol;
+      L.def_full = L.def;
+    }
     ctx->cg_n = n_cols;
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
     ctx->stats.spmv0_rows = n_rows;
@@ -945,7 +1019,31 @@ int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id) {
   if (!ctx || rank < 0 || n_ranks < 1 || rank >= n_ranks) return GMG_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   if (comm_init(ctx->comm, rank, n_ranks, id)) return fail(ctx, GMG_ERR_COMM, "ncclCommInitRank failed");
+  ctx->dist = true;
   return GMG_OK;
+}
+
+int gmg_set_global_sizes(gmg_context *ctx, int64_t n_system_global, int64_t n_level0_global) {
+  if (!ctx || n_system_global < 0 || n_level0_global < 0) return GMG_ERR_INVALID;
+  if (!ctx->dist) return fail(ctx, GMG_ERR_INVALID, "gmg_set_global_sizes: call gmg_comm_init first");
+  ctx->sys_global = n_system_global;
+  ctx->l0_global = n_level0_global;
+  return GMG_OK;
+}
+
+int gmg_partition_range(int64_t n_global, int rank, int n_ranks, int64_t *begin, int64_t *end) {
+  if (n_global < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks || !begin || !end) return GMG_ERR_INVALID;
+  part_range(n_global, rank, n_ranks, begin, end);
+  return GMG_OK;
+}
+
+int gmg_vec_allgather(gmg_context *ctx, int64_t n_global, double *dst_full, const double *src_local) {
+  if (!ctx || n_global < 0) return GMG_ERR_INVALID;
+  if (!ctx->dist) {
+    if (n_global) HIPC(hipMemcpyAsync(dst_full, src_local, sizeof(double) * (size_t)n_global, hipMemcpyDeviceToDevice, ctx->stream));
+    return GMG_OK;
+  }
+  return allgather_full(ctx, dst_full, src_local, n_global);
 }
 
 int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_t *neighbor_rank,

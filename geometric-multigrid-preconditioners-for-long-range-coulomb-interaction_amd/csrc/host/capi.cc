@@ -7,6 +7,7 @@
 #include <string>
 
 #include "laplace_problem.h"
+#include "partition.h"
 
 using namespace step50;
 
@@ -177,5 +178,42 @@ int step50_constrained_mask(step50_problem *h, int8_t *out) {
   return 0;
 }
 void *step50_gmg_context(step50_problem *h) { return DISPATCH(h, gmg); }
+
+// one process per GPU: rank, world size and the 128-byte id of gmg_comm_unique_id (rank 0)
+int step50_set_communicator(step50_problem *h, int rank, int n_ranks, const void *id128) {
+  return guarded(h, [&] {
+    DISPATCH(h, set_communicator(rank, n_ranks, std::string((const char *)id128, 128)));
+    return 0;
+  });
+}
+
+// partition.h on one operator, for the CPU tests of the distributed layout: kind/level as in
+// step50_matrix_shape.  Two calls: sizes first, then the arrays.
+struct step50_local_info { int64_t n_rows, n_cols, nnz, row_begin, n_neighbors, n_send; };
+static LocalOperator g_last_local;
+int step50_localize(step50_problem *h, int kind, int level, int rank, int n_ranks, step50_local_info *out) {
+  return guarded(h, [&] {
+    const CSRMatrix *m = pick_matrix(h, kind, level);
+    if (!m) return 1;
+    g_last_local = localize(*m, rank, n_ranks);
+    out->n_rows = g_last_local.A.n_rows; out->n_cols = g_last_local.A.n_cols; out->nnz = g_last_local.A.nnz();
+    out->row_begin = g_last_local.row_begin; out->n_neighbors = (int64_t)g_last_local.halo.neighbor_rank.size();
+    out->n_send = (int64_t)g_last_local.halo.send_idx.size();
+    return 0;
+  });
+}
+int step50_localize_copy(int64_t *rowptr, int32_t *col, double *val, int32_t *neighbor_rank, int32_t *send_count,
+                         int32_t *send_idx, int32_t *recv_count, int64_t *ghost_global) {
+  const LocalOperator &L = g_last_local;
+  std::memcpy(rowptr, L.A.rowptr.data(), sizeof(int64_t) * L.A.rowptr.size());
+  std::memcpy(col, L.A.col.data(), sizeof(int32_t) * L.A.col.size());
+  std::memcpy(val, L.A.val.data(), sizeof(double) * L.A.val.size());
+  std::memcpy(neighbor_rank, L.halo.neighbor_rank.data(), sizeof(int32_t) * L.halo.neighbor_rank.size());
+  std::memcpy(send_count, L.halo.send_count.data(), sizeof(int32_t) * L.halo.send_count.size());
+  std::memcpy(send_idx, L.halo.send_idx.data(), sizeof(int32_t) * L.halo.send_idx.size());
+  std::memcpy(recv_count, L.halo.recv_count.data(), sizeof(int32_t) * L.halo.recv_count.size());
+  std::memcpy(ghost_global, L.ghost_global.data(), sizeof(int64_t) * L.ghost_global.size());
+  return 0;
+}
 
 }  // extern "C"

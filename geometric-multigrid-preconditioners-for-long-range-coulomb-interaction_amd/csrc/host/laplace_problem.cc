@@ -1,6 +1,7 @@
 // laplace_problem.cc -- see laplace_problem.h.  Reference line numbers are those of
 // /root/reference/src/step-50.cc unless another file is named.
 #include "laplace_problem.h"
+#include "partition.h"
 
 #include <algorithm>
 #include <chrono>
@@ -301,8 +302,8 @@ LaplaceProblem<dim>::LaplaceProblem(const Parameters &p) : par(p) {
 template <int dim>
 LaplaceProblem<dim>::~LaplaceProblem() {
   if (gmg) {
-    if (d_solution) gmg_vec_free(gmg, d_solution);
-    if (d_rhs) gmg_vec_free(gmg, d_rhs);
+    for (double *p : {d_solution, d_rhs, d_full})
+      if (p) gmg_vec_free(gmg, p);
     gmg_destroy(gmg);
   }
 }
@@ -957,9 +958,9 @@ template <int dim>
 int LaplaceProblem<dim>::upload() {
   const int L = triangulation.n_levels();
   if (gmg) {
-    if (d_solution) gmg_vec_free(gmg, d_solution);
-    if (d_rhs) gmg_vec_free(gmg, d_rhs);
-    d_solution = d_rhs = nullptr;
+    for (double *p : {d_solution, d_rhs, d_full})
+      if (p) gmg_vec_free(gmg, p);
+    d_solution = d_rhs = d_full = nullptr;
     gmg_destroy(gmg);
     gmg = nullptr;
   }
@@ -967,10 +968,30 @@ int LaplaceProblem<dim>::upload() {
   int rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
   if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
   const CSRMatrix &S = system_matrix;
-  GMGC(gmg_set_system_matrix(gmg, S.n_rows, S.n_cols, S.rowptr.data(), S.col.data(), S.val.data()));
+  if (distributed) {
+    // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),
+    // levels >= 1, transfers and copy indices are replicated
+    GMGC(gmg_comm_init(gmg, rank, n_ranks, comm_id.data()));
+    GMGC(gmg_set_global_sizes(gmg, S.n_rows, mg_matrices[0].n_rows));
+    const LocalOperator Sl = localize(S, rank, n_ranks);
+    GMGC(gmg_set_system_matrix(gmg, Sl.A.n_rows, Sl.A.n_cols, Sl.A.rowptr.data(), Sl.A.col.data(), Sl.A.val.data()));
+    GMGC(gmg_set_halo_plan(gmg, GMG_SYSTEM, (int)Sl.halo.neighbor_rank.size(), Sl.halo.neighbor_rank.data(),
+                           Sl.halo.send_count.data(), Sl.halo.send_idx.data(), Sl.halo.recv_count.data()));
+    d_begin = Sl.row_begin; d_n = Sl.A.n_rows; d_nvec = Sl.A.n_cols;
+  } else {
+    GMGC(gmg_set_system_matrix(gmg, S.n_rows, S.n_cols, S.rowptr.data(), S.col.data(), S.val.data()));
+    d_begin = 0; d_n = d_nvec = S.n_rows;
+  }
   for (int l = 0; l < L; ++l) {
     const CSRMatrix &A = mg_matrices[(size_t)l];
-    GMGC(gmg_set_level_matrix(gmg, l, A.n_rows, A.n_cols, A.rowptr.data(), A.col.data(), A.val.data()));
+    if (distributed && l == 0) {
+      const LocalOperator Al = localize(A, rank, n_ranks);
+      GMGC(gmg_set_level_matrix(gmg, 0, Al.A.n_rows, Al.A.n_cols, Al.A.rowptr.data(), Al.A.col.data(), Al.A.val.data()));
+      GMGC(gmg_set_halo_plan(gmg, 0, (int)Al.halo.neighbor_rank.size(), Al.halo.neighbor_rank.data(), Al.halo.send_count.data(),
+                             Al.halo.send_idx.data(), Al.halo.recv_count.data()));
+    } else {
+      GMGC(gmg_set_level_matrix(gmg, l, A.n_rows, A.n_cols, A.rowptr.data(), A.col.data(), A.val.data()));
+    }
     const CSRMatrix &I = mg_interface_matrices[(size_t)l];
     if (I.nnz() > 0) GMGC(gmg_set_edge_matrix(gmg, l, I.n_rows, I.n_cols, I.rowptr.data(), I.col.data(), I.val.data()));
     GMGC(gmg_set_copy_indices(gmg, l, (int64_t)copy_global[(size_t)l].size(), copy_global[(size_t)l].data(), copy_level[(size_t)l].data()));
@@ -982,10 +1003,11 @@ int LaplaceProblem<dim>::upload() {
   const int kind = par.smoother == "Jacobi" ? GMG_SMOOTHER_JACOBI : par.smoother == "Chebyshev" ? GMG_SMOOTHER_CHEBYSHEV : GMG_SMOOTHER_SSOR;
   GMGC(gmg_set_smoother(gmg, kind, par.smoother_omega, par.smoother_steps, par.chebyshev_degree, 0.0, 0.0));
   GMGC(gmg_set_coarse(gmg, 1e-10, 1000));  // :962
-  d_n = S.n_rows;
-  GMGC(gmg_vec_alloc(gmg, d_n, &d_solution));
-  GMGC(gmg_vec_alloc(gmg, d_n, &d_rhs));
-  GMGC(gmg_vec_upload(gmg, d_rhs, system_rhs.data(), d_n));
+  GMGC(gmg_vec_alloc(gmg, d_nvec, &d_solution));
+  GMGC(gmg_vec_alloc(gmg, d_nvec, &d_rhs));
+  const int64_t chunk = (S.n_rows + n_ranks - 1) / n_ranks;
+  GMGC(gmg_vec_alloc(gmg, chunk * n_ranks, &d_full));
+  GMGC(gmg_vec_upload(gmg, d_rhs, system_rhs.data() + d_begin, d_n));
   return GMG_OK;
 }
 
@@ -1042,7 +1064,7 @@ int SolverCG_solve(gmg_context *ctx, SolverControl &control, int64_t n, int64_t 
 
 template <int dim>
 int LaplaceProblem<dim>::solve_on_device(CycleReport &rep) {
-  GMGC(gmg_vec_upload(gmg, d_solution, initial_guess.data(), d_n));
+  GMGC(gmg_vec_upload(gmg, d_solution, initial_guess.data() + d_begin, d_n));
   gmg_stats st0;
   gmg_stats_get(gmg, &st0);
   double l1, l2, li;
@@ -1055,7 +1077,7 @@ int LaplaceProblem<dim>::solve_on_device(CycleReport &rep) {
     rc = gmg_cg_solve(gmg, d_solution, d_rhs, 1e-8, 500, par.PreconditionerType == "GMG" ? GMG_PRECOND_GMG : GMG_PRECOND_JACOBI,
                       &control.last_step, &control.initial_value, &control.last_value);
   } else {
-    rc = SolverCG_solve(gmg, control, d_n, d_n, d_solution, d_rhs, par.PreconditionerType);
+    rc = SolverCG_solve(gmg, control, d_n, d_nvec, d_solution, d_rhs, par.PreconditionerType);
   }
   gmg_synchronize(gmg);
   rep.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1068,7 +1090,8 @@ int LaplaceProblem<dim>::solve_on_device(CycleReport &rep) {
   rep.coarse_iterations = st.coarse_iterations - st0.coarse_iterations;
   if (rc != GMG_OK) { last_error = std::string("solve: ") + gmg_last_error(gmg); return rc; }
   GMGC(gmg_vec_norms(gmg, d_solution, d_n, &rep.sol_l1, &rep.sol_l2, &rep.sol_linf));  // :1012-1014
-  GMGC(gmg_vec_download(gmg, solution.data(), d_solution, d_n));
+  GMGC(gmg_vec_allgather(gmg, (int64_t)solution.size(), d_full, d_solution));  // every rank keeps the whole solution
+  GMGC(gmg_vec_download(gmg, solution.data(), d_full, (int64_t)solution.size()));
   return GMG_OK;
 }
 

@@ -121,6 +121,12 @@ class LaplaceProblem {
   bool echo = false;
   gmg_context *gmg = nullptr;
   std::string last_error;
+  // one process per GPU (the reference: one MPI rank per subdomain, src/main.cc:8); the host
+  // setup is replicated, the operators are cut by partition.h at upload()
+  int rank = 0, n_ranks = 1;
+  bool distributed = false;
+  std::string comm_id;  // gmg_comm_unique_id of rank 0, broadcast by the launcher
+  void set_communicator(int rank_, int n_ranks_, const std::string &id) { rank = rank_; n_ranks = n_ranks_; comm_id = id; distributed = true; }
 
   // DoF bookkeeping (Q1: DoFs = vertices)
   struct ActiveCell { int32_t level, index; };
@@ -155,8 +161,8 @@ class LaplaceProblem {
  private:
   struct AtomBins;
   std::unique_ptr<AtomBins> bins;
-  double *d_solution = nullptr, *d_rhs = nullptr;
-  int64_t d_n = 0;
+  double *d_solution = nullptr, *d_rhs = nullptr, *d_full = nullptr;
+  int64_t d_n = 0, d_nvec = 0, d_begin = 0;
   int solve_on_device(CycleReport &rep);
 };
 

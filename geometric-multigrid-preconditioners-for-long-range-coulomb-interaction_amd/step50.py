@@ -192,5 +192,33 @@ class Problem:
             copy_level=[self.copy_indices(l)[1] for l in range(L)],
             constrained=self.constrained_mask())
 
+    def set_communicator(self, rank, n_ranks, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        self._chk(self.L.step50_set_communicator(self.h, C.c_int(rank), C.c_int(n_ranks), buf), "set_communicator")
+
+    def localize(self, kind, level, rank, n_ranks):
+        """partition.h applied to one operator: local CSR ([owned | ghost] columns) + halo plan."""
+        k = {"system": 0, "level": 1}[kind]
+
+        class Info(C.Structure):
+            _fields_ = [(n, C.c_int64) for n in ("n_rows", "n_cols", "nnz", "row_begin", "n_neighbors", "n_send")]
+
+        info = Info()
+        self._chk(self.L.step50_localize(self.h, C.c_int(k), C.c_int(level), C.c_int(rank), C.c_int(n_ranks), C.byref(info)), "localize")
+        rp = np.zeros(info.n_rows + 1, dtype=np.int64)
+        col = np.zeros(max(info.nnz, 1), dtype=np.int32)
+        val = np.zeros(max(info.nnz, 1))
+        nb = np.zeros(max(info.n_neighbors, 1), dtype=np.int32)
+        sc, rc = np.zeros_like(nb), np.zeros_like(nb)
+        si = np.zeros(max(info.n_send, 1), dtype=np.int32)
+        gg = np.zeros(max(info.n_cols - info.n_rows, 1), dtype=np.int64)
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        self.L.step50_localize_copy(P(rp, C.c_int64), P(col, C.c_int32), P(val, C.c_double), P(nb, C.c_int32), P(sc, C.c_int32),
+                                    P(si, C.c_int32), P(rc, C.c_int32), P(gg, C.c_int64))
+        nn = info.n_neighbors
+        return SimpleNamespace(n_rows=info.n_rows, n_cols=info.n_cols, rowptr=rp, col=col[:info.nnz], val=val[:info.nnz],
+                               nnz=info.nnz, row_begin=info.row_begin, neighbor_rank=nb[:nn], send_count=sc[:nn],
+                               recv_count=rc[:nn], send_idx=si[:info.n_send], ghost_global=gg[:info.n_cols - info.n_rows])
+
     def gmg_context(self):
         return C.c_void_p(self.L.step50_gmg_context(self.h))

@@ -130,6 +130,16 @@ int gmg_cg_solve(gmg_context *ctx, double *x, const double *b, double rel_tol, i
 #define GMG_UNIQUE_ID_BYTES 128
 int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broadcast by the host */
 int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
+/* Distributed layout: the system matrix / outer-CG vectors and level 0 (matrix,
+ * coarse CG) are row-partitioned in equal chunks -- gmg_partition_range gives the canonical
+ * owned range, mirroring locally_owned_dofs() of the reference (:656-657) -- while levels >= 1,
+ * the transfers and the copy-index lists are passed whole (global numbering) on every rank.
+ * Call order: gmg_comm_init, gmg_set_global_sizes, then the gmg_set_* of the operators.   */
+int gmg_set_global_sizes(gmg_context *ctx, int64_t n_system_global, int64_t n_level0_global);
+int gmg_partition_range(int64_t n_global, int rank, int n_ranks, int64_t *begin, int64_t *end);
+/* dst_full (n_global entries, padded to n_ranks * ceil(n_global / n_ranks)) <- every rank's
+ * owned slice; the reference does this with a ghosted vector assignment (:1026-1028).     */
+int gmg_vec_allgather(gmg_context *ctx, int64_t n_global, double *dst_full, const double *src_local);
 /* Epetra_Import plan of one operator: for each neighbour the owned local rows to send and
  * the number of ghost values received; ghosts are stored behind the owned entries in
  * neighbour order.  `which` as in gmg_spmv.                                              */
