@@ -47,7 +47,7 @@ def build_device(force=False, verbose=False):
 def build_host(force=False, verbose=False):
     if not os.path.isdir(HOST) or not _sources(HOST, (".cc",)):
         return None
-    srcs = _sources(HOST, (".cc", ".h")) + [os.path.join(HERE, "..", "include", "gmg_coulomb.h")]
+    srcs = _sources(HOST, (".cc", ".h", ".inc")) + [os.path.join(HERE, "..", "include", "gmg_coulomb.h")]
     lib_srcs = [s for s in _sources(HOST, (".cc",)) if not s.endswith("main.cc")]
     if force or _newer(LIB_HOST, srcs):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-fopenmp",

@@ -477,7 +477,7 @@ int level_v_step(gmg_context *ctx, int l) {
   Level &L = ctx->lv[(size_t)l];
   if (l == 0) return coarse_level_solve(ctx);
   Level &C = ctx->lv[(size_t)l - 1];
-  double *c_def = (l == 1) ? C.def_full : C.def, *c_sol = (l == 1) ? C.sol_full : C.sol;
+  double *c_def = (l == 1) ? C.def_full : C.def;
   const int g = grid_for(L.n);
   CHK(smooth_level(ctx, l, &L.sol, L.def, true, &L.w1));  // pre_smooth->apply (Jacobi may swap sol <-> w1)
   if (L.has_I) {
@@ -489,6 +489,7 @@ int level_v_step(gmg_context *ctx, int l) {
   }
   CHK(spmv(ctx, C.Pt, kStore, L.t, c_def, c_def));            // restrict_and_add
   CHK(level_v_step(ctx, l - 1));
+  const double *c_sol = (l == 1) ? C.sol_full : C.sol;        // read AFTER the recursion: Jacobi swaps C.sol
   CHK(spmv(ctx, C.P, kAddTo, c_sol, L.sol, nullptr, L.sol));  // u += P u_c
   if (L.has_I) {
     CHK(spmv(ctx, L.It, kResid, L.sol, L.def, nullptr, L.def));  // defect -= I^T u

@@ -102,6 +102,15 @@ int step50_run_cycle(step50_problem *h, int cycle, int on_device) {
 int step50_solve_again(step50_problem *h) {
   return guarded(h, [&] { return DISPATCH(h, solve_again()); });
 }
+// CPU-only continuation of a cycle for tests: inject a solution, then estimator + energy
+int step50_finish_cycle_with(step50_problem *h, const double *x, int64_t n) {
+  return guarded(h, [&] {
+    std::vector<double> v(x, x + n);
+    DISPATCH(h, set_solution(v));
+    DISPATCH(h, finish_cycle());
+    return 0;
+  });
+}
 int step50_n_reports(step50_problem *h) { return (int)DISPATCH(h, reports).size(); }
 
 struct step50_report {

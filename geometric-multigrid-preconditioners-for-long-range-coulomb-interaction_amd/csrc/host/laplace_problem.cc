@@ -1249,9 +1249,22 @@ int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
   if (rc != GMG_OK) return rc;
   rc = solve();
   if (rc != GMG_OK) return rc;
-  estimate_error_and_mark_cells();
-  if (lammpsinput && number_of_atoms < 300) postprocess_electrostatic_energy();  // :1554-1555
+  finish_cycle();
   return GMG_OK;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::finish_cycle() {
+  estimate_error_and_mark_cells();                                               // :1552
+  if (lammpsinput && number_of_atoms < 300) postprocess_electrostatic_energy();  // :1554-1555
+}
+
+// Test hook: a solution computed elsewhere (the CPU oracle in tests/) takes the place of solve();
+// x is the pre-distribute vector as the solver returns it.
+template <int dim>
+void LaplaceProblem<dim>::set_solution(const std::vector<double> &x) {
+  solution = x;
+  distribute_constraints(solution);
 }
 
 template <int dim>

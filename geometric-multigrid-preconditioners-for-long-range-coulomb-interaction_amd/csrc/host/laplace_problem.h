@@ -103,6 +103,8 @@ class LaplaceProblem {
   void refine_grid(unsigned int cycle);                                  // :1095-1121
   void postprocess_electrostatic_energy();                               // :1310-1420
   int run_cycle(unsigned int cycle, bool on_device = true);              // one iteration of the loop in run()
+  void finish_cycle();                                   // estimator + energy, the tail of the loop body
+  void set_solution(const std::vector<double> &x);       // test hook, see laplace_problem.cc
   int solve_again();  // repeat the solve of the current cycle from the same initial guess (bench step)
 
   // ---- data, named as in the reference where it exists (include/step_50.h:146-200)

@@ -125,6 +125,11 @@ class Problem:
         self._chk(self.L.step50_run_cycle(self.h, C.c_int(cycle), C.c_int(1 if on_device else 0)), f"cycle {cycle}")
         return self.report(-1)
 
+    def finish_cycle_with(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._chk(self.L.step50_finish_cycle_with(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), C.c_int64(len(x))), "finish_cycle")
+        return self.report(-1)
+
     def solve_again(self):
         self._chk(self.L.step50_solve_again(self.h), "solve")
         return self.report(-1)

@@ -226,6 +226,7 @@ def test_single_rank_communicator_path(hier45):
     communicator must give the same iteration count as the fused single-GPU path."""
     c = capi().Context(1)
     c.comm_init(0, 1, capi().Context.unique_id())
+    c.set_global_sizes(hier45.system_matrix.n_rows, hier45.level_matrices[0].n_rows)
     c.load_hierarchy(hier45)
     n = hier45.system_matrix.n_rows
     vb, vx = c.vector(n, hier45.system_rhs), c.vector(n)
