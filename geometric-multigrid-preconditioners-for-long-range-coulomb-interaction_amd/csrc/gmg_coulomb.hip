@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +31,13 @@ struct DevCSR {
   int n_tiles = 0, tiles_per_xcd = 0, grid = 0;
   bool valid = false;
   HaloPlan halo;
+  // SELL-64 copy (regular-width operators only), see gmg_device.hpp
+  bool sell = false;
+  int32_t *slice_ptr = nullptr;  // in quads
+  double2 *val2 = nullptr;
+  int4 *col4 = nullptr;
+  int n_slices = 0, sell_grid = 0;
+  int64_t sell_quads = 0;
 };
 
 struct SgsPlan {
@@ -130,13 +138,16 @@ void free_csr(DevCSR &m) {
   if (m.col) (void)hipFree(m.col);
   if (m.val) (void)hipFree(m.val);
   if (m.tile_row) (void)hipFree(m.tile_row);
+  if (m.slice_ptr) (void)hipFree(m.slice_ptr);
+  if (m.val2) (void)hipFree(m.val2);
+  if (m.col4) (void)hipFree(m.col4);
   free_halo(m.halo);
   m = DevCSR();
 }
 
 // Host CSR -> device CSR + LDS-window tiling.
 int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col,
-               const double *val) {
+               const double *val, bool keep_csr = false) {
   if (n_rows < 0 || n_cols < 0 || !rowptr) return fail(ctx, GMG_ERR_INVALID, "upload_csr: bad arguments");
   const int64_t nnz = rowptr[n_rows];
   if (nnz >= (int64_t)1 << 31 || n_rows >= (int64_t)1 << 31 || n_cols >= (int64_t)1 << 31)
@@ -184,6 +195,55 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   HIPC(hipMemcpyAsync(m.tile_row, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));  // host staging buffers die here
   m.valid = true;
+  // SELL-64 copy when the rows are regular enough (level-0 lattice, active-mesh matrix)
+  const char *no_sell = std::getenv("GMG_DISABLE_SELL");
+  if (n_rows >= 1024 && !(no_sell && no_sell[0] == '1')) {
+    const int64_t n_slices = (n_rows + 63) / 64;
+    std::vector<int32_t> sp((size_t)n_slices + 1, 0);
+    int64_t quads = 0;
+    for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
+      int64_t w = 0;
+      for (int64_t r2 = sidx * 64; r2 < std::min<int64_t>(n_rows, sidx * 64 + 64); ++r2) w = std::max(w, rowptr[r2 + 1] - rowptr[r2]);
+      quads += (w + 3) / 4;
+      sp[(size_t)sidx + 1] = (int32_t)quads;
+    }
+    if (quads * 256 <= (int64_t)(1.12 * (double)nnz) && quads * 256 < ((int64_t)1 << 31)) {
+      std::vector<double> v2((size_t)quads * 256, 0.0);
+      std::vector<int32_t> c4((size_t)quads * 256, 0);
+      for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
+        const int64_t q0 = sp[(size_t)sidx], nq = sp[(size_t)sidx + 1] - q0;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int64_t r2 = sidx * 64 + lane;
+          const int64_t k0 = r2 < n_rows ? rowptr[r2] : 0, len = r2 < n_rows ? rowptr[r2 + 1] - k0 : 0;
+          const int32_t padcol = r2 < std::min(n_rows, n_cols) ? (int32_t)r2 : 0;
+          for (int64_t j = 0; j < 4 * nq; ++j) {
+            const int64_t qq = q0 + j / 4, e = j & 3;
+            const size_t ov = (size_t)(((2 * qq + (e >> 1)) * 64 + lane) * 2 + (e & 1));
+            const size_t oc = (size_t)((qq * 64 + lane) * 4 + e);
+            if (j < len) { v2[ov] = val[k0 + j]; c4[oc] = col[k0 + j]; }
+            else { v2[ov] = 0.0; c4[oc] = padcol; }
+          }
+        }
+      }
+      HIPC(hipMalloc(&m.slice_ptr, sizeof(int32_t) * sp.size()));
+      HIPC(hipMalloc(&m.val2, sizeof(double) * v2.size()));
+      HIPC(hipMalloc(&m.col4, sizeof(int32_t) * c4.size()));
+      HIPC(hipMemcpyAsync(m.slice_ptr, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.val2, v2.data(), sizeof(double) * v2.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.col4, c4.data(), sizeof(int32_t) * c4.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipStreamSynchronize(ctx->stream));
+      m.sell = true;
+      m.n_slices = (int)n_slices;
+      m.sell_quads = quads;
+      // one wave per >= 1 slice; at most 1024 workgroups (4 per CU)
+      const int per_xcd = (int)((n_slices + 7) / 8);
+      m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
+      if (!keep_csr) {  // the CSR copy is only kept where the SGS sweeps need it (levels >= 1)
+        (void)hipFree(m.col); (void)hipFree(m.val); (void)hipFree(m.tile_row);
+        m.col = nullptr; m.val = nullptr; m.tile_row = nullptr;
+      }
+    }
+  }
   return GMG_OK;
 }
 
@@ -215,9 +275,20 @@ int alloc_vec(gmg_context *ctx, double **p, int64_t n) {
 
 // ---- SpMV launcher ---------------------------------------------------------------------
 
+// one launcher for both layouts; returns the grid (= number of reduction partials when CG != 0)
+template <int MODE, int CG>
+int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
+  if (m.sell) {
+    SellArgs sa{m.slice_ptr, m.val2, m.col4, m.n_slices, (int)m.n_rows, a};
+    hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    return m.sell_grid;
+  }
+  hipLaunchKernelGGL((spmv_tile_kernel<MODE, CG>), dim3(m.grid), dim3(kThreads), 0, ctx->stream, a);
+  return m.grid;
+}
 template <int MODE>
 void launch_spmv_mode(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
-  hipLaunchKernelGGL((spmv_tile_kernel<MODE, 0>), dim3(m.grid), dim3(kThreads), 0, ctx->stream, a);
+  (void)launch_op<MODE, 0>(ctx, m, a);
 }
 
 SpmvArgs base_args(const DevCSR &m, const double *x, double *y) {
@@ -400,9 +471,9 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
       a.tol = ctx->coarse_tol; a.maxit = maxit;
       const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
       if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
-      hipLaunchKernelGGL((spmv_tile_kernel<kStore, 1>), dim3(A.grid), dim3(kThreads), 0, ctx->stream, a);
+      const int n_part_dh = launch_op<kStore, 1>(ctx, A, a);
       if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
-      CGUpdateArgs ua{x, ctx->cg_g, a.dnew, ctx->cg_h, n, ctx->st, ctx->part_a, A.grid, ctx->part_b};
+      CGUpdateArgs ua{x, ctx->cg_g, a.dnew, ctx->cg_h, n, ctx->st, ctx->part_a, n_part_dh, ctx->part_b};
       const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
       if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
       hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
@@ -691,7 +762,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
   if (!ctx || level < 0 || level >= ctx->n_levels) return GMG_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
   Level &L = ctx->lv[(size_t)level];
-  CHK(upload_csr(ctx, L.A, n_rows, n_cols, rowptr, col, val));
+  CHK(upload_csr(ctx, L.A, n_rows, n_cols, rowptr, col, val, level > 0));
   L.n = n_rows;
   L.n_vec = n_cols;
   CHK(setup_diag(ctx, n_rows, rowptr, col, val, &L.invd, &L.cheb_lmax));

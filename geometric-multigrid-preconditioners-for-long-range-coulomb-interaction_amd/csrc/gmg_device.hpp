@@ -270,6 +270,130 @@ __global__ __launch_bounds__(kThreads) void spmv_tile_kernel(SpmvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- SELL-64 SpMV (regular-width operators)
+//
+// Internal HBM layout for operators whose rows have (nearly) the same length -- the level-0
+// lattice and the active-mesh matrix: rows are grouped in slices of 64 (one wavefront), every
+// slice is padded to its longest row rounded up to a multiple of 4 and stored "quad-major":
+//   col4[q * 64 + lane]           = 4 consecutive column indices of the lane's row   (16 B per lane)
+//   val2[(2 q + h) * 64 + lane]   = the matching values, two per 16-B load (h = 0, 1)
+// with q running over the quads of slice 0, then slice 1, ...  The matrix therefore streams
+// with fully coalesced 16-B-per-lane loads AND, because lane = row, the gathers x[col] of a
+// lattice operator are coalesced too (consecutive rows have consecutive columns: ~6 cache
+// lines per wave instruction instead of ~24 with the CSR window).  Each lane adds its row's
+// products in CSR order (padding = +0.0 at the end), so results stay bit-identical to the
+// sequential CPU sum.  A wave owns a CONTIGUOUS run of slices and streams through their quads
+// as one software-pipelined loop (two quads = 6 KB per wave prefetched ahead, across slice
+// boundaries): no LDS, no barriers, no pipeline refill per slice.  Chosen at upload when the
+// padding costs < 12 %.
+struct SellArgs {
+  const int32_t *qptr;  // n_slices + 1, in quads
+  const double2 *val2;
+  const int4 *col4;
+  int n_slices;
+  int n_rows;
+  SpmvArgs a;  // vectors, epilogue operands, CG state (rowptr/col/val unused)
+};
+
+template <int MODE, int CG>
+__global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
+  __shared__ double red[4];
+  const SpmvArgs &a = sa.a;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr bool XFORM = (CG == 1);
+  double beta = 0.0;
+  if constexpr (CG == 1) {
+    if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
+  }
+  if constexpr (CG == 2) {
+    if (a.st->done) return;
+  }
+  // XCD-aware contiguous ownership: XCD -> eighth of the slices, wave -> contiguous run in it
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
+  const int per_xcd = (sa.n_slices + 7) >> 3;
+  const int x0 = xcd * per_xcd, x1 = min(x0 + per_xcd, sa.n_slices);
+  const int waves = nb * 4;
+  const int per_wave = (max(x1 - x0, 0) + waves - 1) / waves;
+  const int s0 = x0 + (lb * 4 + wid) * per_wave, s1 = min(s0 + per_wave, x1);
+  double dot_acc = 0.0;
+
+  auto X = [&](int c) -> double {
+    if constexpr (XFORM) return beta * a.x[c] - a.g[c];
+    else return a.x[c];
+  };
+
+  if (s0 < s1) {
+    const int Q1 = sa.qptr[s1];
+    int q = sa.qptr[s0];
+    int s = s0;
+    int qe = sa.qptr[s0 + 1];  // end of the current slice
+    double acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
+    const double2 *vbase = sa.val2 + lane;
+    const int4 *cbase = sa.col4 + lane;
+    double2 va0, va1, vb0, vb1, vc0, vc1;
+    int4 ca, cb, cc;
+    va0 = va1 = vb0 = vb1 = vc0 = vc1 = double2{0.0, 0.0};
+    ca = cb = cc = int4{0, 0, 0, 0};
+
+#define GMG_LOADQ(V0, V1, C, Q)                       \
+  {                                                   \
+    C = cbase[(size_t)(Q) * 64];                      \
+    V0 = vbase[(size_t)(2 * (Q)) * 64];               \
+    V1 = vbase[(size_t)(2 * (Q) + 1) * 64];           \
+  }
+    auto finish_slice = [&]() {
+      const int r = s * 64 + lane;
+      if (r < sa.n_rows) {
+        if constexpr (XFORM) {
+          const double dn = beta * a.x[r] - a.g[r];
+          a.dnew[r] = dn; a.y[r] = acc; dot_acc += dn * acc;
+        } else if constexpr (CG == 2) {
+          a.y[r] = acc; dot_acc += a.x[r] * acc;
+        } else if constexpr (MODE == kStore) a.y[r] = acc;
+        else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;
+        else if constexpr (MODE == kAddTo) a.y[r] = a.b[r] + acc;
+        else if constexpr (MODE == kJacobi) a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
+        else if constexpr (MODE == kCheb) {
+          const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
+          a.w[r] = wn; a.y[r] = a.x[r] + wn;
+        }
+      }
+      ++s;
+      if (s < s1) {
+        qe = sa.qptr[s + 1];
+        acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
+      }
+    };
+    // gathers of the current quad first, THEN the prefetch two quads ahead: the in-order
+    // vmcnt wait for the gathers leaves the younger stream loads in flight
+#define GMG_STEP(V0, V1, C, NV0, NV1, NC)                              \
+  {                                                                    \
+    const double x0_ = X(C.x), x1_ = X(C.y), x2_ = X(C.z), x3_ = X(C.w); \
+    if (q + 2 < Q1) GMG_LOADQ(NV0, NV1, NC, q + 2);                    \
+    acc += V0.x * x0_; acc += V0.y * x1_; acc += V1.x * x2_; acc += V1.y * x3_; \
+    ++q;                                                               \
+    while (q == qe && s < s1) finish_slice();                          \
+  }
+    GMG_LOADQ(va0, va1, ca, q);
+    if (q + 1 < Q1) GMG_LOADQ(vb0, vb1, cb, q + 1);
+    // empty leading slices (width 0) cannot occur: every row has a diagonal entry; guard anyway
+    while (q == qe && s < s1) finish_slice();
+    while (q < Q1) {
+      GMG_STEP(va0, va1, ca, vc0, vc1, cc);
+      if (q >= Q1) break;
+      GMG_STEP(vb0, vb1, cb, va0, va1, ca);
+      if (q >= Q1) break;
+      GMG_STEP(vc0, vc1, cc, vb0, vb1, cb);
+    }
+#undef GMG_STEP
+#undef GMG_LOADQ
+  }
+  if constexpr (CG != 0) {
+    const double sblock = block_sum(dot_acc, red);
+    if (threadIdx.x == 0) a.part_out[blockIdx.x] = sblock;
+  }
+}
+
 // Distributed coarse CG: opens the iteration and forms d = beta d - g on the owned range;
 // the ghost entries of d arrive by halo exchange before the SpMV (CG = 2).
 struct CGDirArgs {

@@ -36,8 +36,8 @@ int coarse_solve_distributed(gmg_context *ctx, double *x, const double *b, int *
       SpmvArgs a = base_args(A, d, ctx->cg_h);
       a.st = ctx->st;
       a.part_out = ctx->part_a;
-      hipLaunchKernelGGL((spmv_tile_kernel<kStore, 2>), dim3(A.grid), dim3(kThreads), 0, ctx->stream, a);
-      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, A.grid, 1, 0u, s_dh);
+      const int n_part_dh = launch_op<kStore, 2>(ctx, A, a);
+      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, n_part_dh, 1, 0u, s_dh);
       if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
       CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, s_dh, 1, ctx->part_b};
       hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
