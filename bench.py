@@ -100,6 +100,7 @@ def main():
     dt = time.perf_counter() - t0
     st = ctx.stats()
     ctx.set_profiling(0)
+    hbm_read, hbm_copy = ctx.calibrate_hbm(1 << 30, 10) if rank == 0 else (0.0, 0.0)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -113,12 +114,16 @@ def main():
     roof = None
     if st.spmv0_samples > 0:
         t_k = st.spmv0_ms_total / st.spmv0_samples * 1e-3
-        # the level-0 kernel is SpMV + fused direction update: SpMV bytes + 16 N (reads g, writes d)
-        alg = spmv_bytes(n0, nnz0) + 16 * n0
+        # fused variant: SpMV + direction update in one kernel = SpMV bytes + 16 N (reads g, writes d);
+        # unfused variant (large level 0): plain SpMV + partial d.h
+        fused = st.coarse_variant == 1
+        alg = spmv_bytes(n0, nnz0) + (16 * n0 if fused else 0)
         ach = alg / t_k / 1e9
-        roof = {"bound": "hbm", "kernel": "spmv_tile_kernel<kStore,1> (level-0 SpMV + CG direction update)",
+        kname = ("spmv_sell_kernel" if st.spmv0_layout == 1 else "spmv_tile_kernel") + ("<kStore,1>" if fused else "<kStore,2>")
+        roof = {"bound": "hbm", "kernel": kname + (" (level-0 SpMV + CG direction update)" if fused else " (level-0 SpMV + d.h partials)"),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "bytes_per_launch": alg, "avg_launch_us": round(t_k * 1e6, 2),
+                "traffic": None, "bytes_per_launch": alg, "measured_stream_read_GBps": round(hbm_read, 1),
+                "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),
                 "launches_sampled": int(st.spmv0_samples)}
         if st.cgupd_samples > 0:
             t_u = st.cgupd_ms_total / st.cgupd_samples * 1e-3

@@ -29,14 +29,15 @@ SYMBOLS = [
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
     "gmg_comm_unique_id", "gmg_comm_init", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
     "gmg_vec_allgather",
-    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning",
+    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_calibrate_hbm",
 ]
 
 
 class Stats(C.Structure):
     _fields_ = [("coarse_solves", C.c_int64), ("coarse_iterations", C.c_int64), ("vcycles", C.c_int64),
                 ("spmv0_samples", C.c_int64), ("spmv0_ms_total", C.c_double), ("spmv0_rows", C.c_int64),
-                ("spmv0_nnz", C.c_int64), ("cgupd_samples", C.c_int64), ("cgupd_ms_total", C.c_double)]
+                ("spmv0_nnz", C.c_int64), ("cgupd_samples", C.c_int64), ("cgupd_ms_total", C.c_double),
+                ("coarse_variant", C.c_int64), ("spmv0_layout", C.c_int64)]
 
 
 class GMGError(RuntimeError):
@@ -284,6 +285,11 @@ class Context:
 
     def set_profiling(self, every):
         self._chk(self.L.gmg_set_profiling(self.h, C.c_int(every)))
+
+    def calibrate_hbm(self, n_bytes=1 << 30, reps=10):
+        r, c = C.c_double(0), C.c_double(0)
+        self._chk(self.L.gmg_calibrate_hbm(self.h, C.c_int64(n_bytes), C.c_int(reps), C.byref(r), C.byref(c)))
+        return r.value, c.value
 
     def set_tuning(self, coarse_chunk=0, use_graph=0):
         self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(use_graph)))

@@ -91,6 +91,7 @@ struct gmg_context {
   // tuning / measurement
   int coarse_chunk = 0;
   int use_graph = 0;
+  int cg_variant = 0;  // 0 auto, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration
   int last_coarse_iters = 0;
   int prof_every = 0;
   std::vector<hipEvent_t> ev_a, ev_b;  // sampled level-0 SpMV launches
@@ -199,6 +200,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   const char *no_sell = std::getenv("GMG_DISABLE_SELL");
   if (n_rows >= 1024 && !(no_sell && no_sell[0] == '1')) {
     const int64_t n_slices = (n_rows + 63) / 64;
+    const char *dbg = std::getenv("GMG_DEBUG_NOGATHER");  // timing experiments only: every column -> own row
+    const bool debug_nogather = dbg && dbg[0] == '1';
     std::vector<int32_t> sp((size_t)n_slices + 1, 0);
     int64_t quads = 0;
     for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
@@ -220,7 +223,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
             const int64_t qq = q0 + j / 4, e = j & 3;
             const size_t ov = (size_t)(((2 * qq + (e >> 1)) * 64 + lane) * 2 + (e & 1));
             const size_t oc = (size_t)((qq * 64 + lane) * 4 + e);
-            if (j < len) { v2[ov] = val[k0 + j]; c4[oc] = col[k0 + j]; }
+            if (j < len) { v2[ov] = val[k0 + j]; c4[oc] = debug_nogather ? padcol : col[k0 + j]; }
             else { v2[ov] = 0.0; c4[oc] = padcol; }
           }
         }
@@ -434,15 +437,40 @@ int smooth_level(gmg_context *ctx, int l, double **u_io, const double *rhs, bool
   return GMG_OK;
 }
 
+void collect_profile_samples(gmg_context *ctx) {
+  for (int i = 0; i < ctx->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_a[(size_t)i], ctx->ev_b[(size_t)i]) == hipSuccess) {
+      ctx->stats.spmv0_ms_total += ms;
+      ctx->stats.spmv0_samples++;
+    }
+  }
+  for (int i = 0; i < ctx->ev2_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_c[(size_t)i], ctx->ev_d[(size_t)i]) == hipSuccess) {
+      ctx->stats.cgupd_ms_total += ms;
+      ctx->stats.cgupd_samples++;
+    }
+  }
+}
+
+constexpr int64_t kUnfusedMinRowsDecl = 400000;  // == kUnfusedMinRows in gmg_dist.hpp
+
 // ---- coarse solver (A9): device-resident classic CG on level 0 -----------------------------
 
-int coarse_solve_distributed(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out);
+int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out);
+void collect_profile_samples(gmg_context *ctx);
 
 int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out) {
   Level &L0 = ctx->lv[0];
   const DevCSR &A = L0.A;
   if (!A.valid) return fail(ctx, GMG_ERR_INVALID, "level-0 matrix not set");
-  if (ctx->comm.ready) return coarse_solve_distributed(ctx, x, b, iters_out, res_out);
+  if (ctx->dist || (ctx->cg_variant == 0 && L0.n >= kUnfusedMinRowsDecl) || ctx->cg_variant == 2)
+  {
+    ctx->stats.coarse_variant = 2;
+    return coarse_solve_unfused(ctx, x, b, iters_out, res_out);
+  }
+  ctx->stats.coarse_variant = 1;
   const int64_t n = L0.n;
   const int g_upd = grid_for((n / 2 + 0));
   const int g_init = grid_for(n);
@@ -486,20 +514,7 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
     if (launched > maxit + 1) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
     chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 4;
   }
-  for (int i = 0; i < ctx->ev_used; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_a[(size_t)i], ctx->ev_b[(size_t)i]) == hipSuccess) {
-      ctx->stats.spmv0_ms_total += ms;
-      ctx->stats.spmv0_samples++;
-    }
-  }
-  for (int i = 0; i < ctx->ev2_used; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_c[(size_t)i], ctx->ev_d[(size_t)i]) == hipSuccess) {
-      ctx->stats.cgupd_ms_total += ms;
-      ctx->stats.cgupd_samples++;
-    }
-  }
+  collect_profile_samples(ctx);
   ctx->last_coarse_iters = ctx->st_host->iters;
   ctx->stats.coarse_solves++;
   ctx->stats.coarse_iterations += ctx->st_host->iters;
@@ -784,6 +799,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
     ctx->stats.spmv0_rows = n_rows;
     ctx->stats.spmv0_nnz = rowptr[n_rows];
+    ctx->stats.spmv0_layout = L.A.sell ? 1 : 0;
     ctx->last_coarse_iters = 0;
   }
   HIPC(hipStreamSynchronize(ctx->stream));
@@ -1142,9 +1158,9 @@ int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_
 
 int gmg_stats_reset(gmg_context *ctx) {
   if (!ctx) return GMG_ERR_INVALID;
-  const int64_t r = ctx->stats.spmv0_rows, z = ctx->stats.spmv0_nnz;
+  const int64_t r = ctx->stats.spmv0_rows, z = ctx->stats.spmv0_nnz, v = ctx->stats.coarse_variant, y = ctx->stats.spmv0_layout;
   ctx->stats = gmg_stats{};
-  ctx->stats.spmv0_rows = r; ctx->stats.spmv0_nnz = z;
+  ctx->stats.spmv0_rows = r; ctx->stats.spmv0_nnz = z; ctx->stats.coarse_variant = v; ctx->stats.spmv0_layout = y;
   return GMG_OK;
 }
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out) {
@@ -1163,10 +1179,46 @@ int gmg_set_profiling(gmg_context *ctx, int sample_every) {
   }
   return GMG_OK;
 }
+int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_gbps, double *copy_gbps) {
+  if (!ctx || n_bytes < (1 << 20) || reps < 1) return GMG_ERR_INVALID;
+  const int64_t n2 = n_bytes / 16;
+  double2 *a = nullptr, *b = nullptr;
+  HIPC(hipMalloc(&a, (size_t)n2 * 16));
+  HIPC(hipMalloc(&b, (size_t)n2 * 16));
+  HIPC(hipMemsetAsync(a, 0, (size_t)n2 * 16, ctx->stream));
+  HIPC(hipMemsetAsync(b, 0, (size_t)n2 * 16, ctx->stream));
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  float ms = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0 warms up
+    HIPC(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r)
+      hipLaunchKernelGGL(stream_read_kernel, dim3(kMaxPartials), dim3(kThreads), 0, ctx->stream, (const double2 *)a, n2, ctx->part_a);
+    HIPC(hipEventRecord(e1, ctx->stream));
+    HIPC(hipEventSynchronize(e1));
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+  }
+  if (read_gbps) *read_gbps = (double)n2 * 16 * reps / (ms * 1e-3) / 1e9;
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPC(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r)
+      hipLaunchKernelGGL(stream_copy_kernel, dim3(kMaxPartials * 2), dim3(kThreads), 0, ctx->stream, (const double2 *)a, b, n2);
+    HIPC(hipEventRecord(e1, ctx->stream));
+    HIPC(hipEventSynchronize(e1));
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+  }
+  if (copy_gbps) *copy_gbps = (double)n2 * 32 * reps / (ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  return GMG_OK;
+}
+
 int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph) {
   if (!ctx) return GMG_ERR_INVALID;
   ctx->coarse_chunk = coarse_chunk;
-  ctx->use_graph = use_graph;
+  ctx->use_graph = use_graph & 1;
+  ctx->cg_variant = (use_graph >> 4) & 3;  // bits 4-5: coarse-CG variant (0 auto, 1 fused, 2 unfused)
   return GMG_OK;
 }
 

@@ -22,7 +22,7 @@ constexpr int kThreads = 256;      // 4 waves
 constexpr int kTileNnz = 4096;     // LDS row window, doubles (32 KiB) -> 4 workgroups / CU
 constexpr int kTileCap = 4092;     // max nnz of a regular tile (window start is rounded down to 4)
 constexpr int kPasses = kTileNnz / (kThreads * 4);
-constexpr int kMaxPartials = 1024; // upper bound of any grid that emits reduction partials
+constexpr int kMaxPartials = 2048; // upper bound of any grid that emits reduction partials
 
 // ---------------------------------------------------------------- reductions
 
@@ -567,6 +567,23 @@ __global__ __launch_bounds__(kThreads) void reduce_final_kernel(const double *pa
     }
     if (threadIdx.x == 0) out[j] = r;
   }
+}
+
+// ---------------------------------------------------------------- HBM calibration (measurement only)
+// Pure streaming read (16 B / lane, grid-stride) and copy: the ceiling the SpMV is compared with
+// on the device it actually runs on (bench.py reports it next to the 8 TB/s spec figure).
+__global__ __launch_bounds__(kThreads) void stream_read_kernel(const double2 *x, int64_t n2, double *part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+    const double2 v = x[i];
+    acc += v.x + v.y;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kThreads) void stream_copy_kernel(const double2 *x, double2 *y, int64_t n2) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) y[i] = x[i];
 }
 
 // ---------------------------------------------------------------- SSOR (level-scheduled SGS)

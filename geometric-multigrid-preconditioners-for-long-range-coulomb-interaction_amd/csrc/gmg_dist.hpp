@@ -1,17 +1,24 @@
-// gmg_dist.hpp -- coarse CG on a row-partitioned level-0 operator (one process per GPU).
+// gmg_dist.hpp -- coarse CG with the direction update as its own kernel.
 //
-// Same SolverCG operation order as the single-GPU path (gmg_device.hpp), but the direction
-// update is its own kernel so that the ghost entries of d can be imported between it and the
-// SpMV, and every reduction goes workgroup partials -> one device scalar -> ncclAllReduce
-// (sum, fp64, count 1) -> read by the next kernel as a one-element "partials" array.  No host
-// synchronisation inside a chunk of iterations.  Included by gmg_coulomb.hip.
+// Same SolverCG operation order as the fused path (gmg_device.hpp), used in two situations:
+//   * row-partitioned level 0 (one process per GPU): the ghost entries of d must be imported
+//     between the direction update and the SpMV; every reduction goes workgroup partials ->
+//     one device scalar -> ncclAllReduce (sum, fp64, count 1) -> read by the next kernel as a
+//     one-element "partials" array.  No host synchronisation inside a chunk of iterations.
+//   * large single-GPU level 0 (>= kUnfusedMinRows): the fused kernel gathers d AND g per
+//     nonzero, which costs more (TA-bound, measured 149 vs 117+9 us at 121^3) than streaming
+//     24 N bytes once; small problems keep the fused 2-kernel iteration (launch-bound).
+// Included by gmg_coulomb.hip.
 #pragma once
 
 namespace {
 
-int coarse_solve_distributed(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out) {
+constexpr int64_t kUnfusedMinRows = 400000;
+
+int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out) {
   Level &L0 = ctx->lv[0];
   DevCSR &A = L0.A;
+  const bool comm = ctx->dist;
   const int64_t n = L0.n;
   const int g_vec = grid_for(n);
   const int g_upd = grid_for(n / 2);
@@ -20,29 +27,51 @@ int coarse_solve_distributed(gmg_context *ctx, double *x, const double *b, int *
 
   CGInitArgs ia{b, x, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, n, ctx->st, ctx->part_b};
   hipLaunchKernelGGL(cg_init_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, ia);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_vec, 1, 0u, s_gg);
-  if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+  // where the consumers find the reduced scalars: all-reduced single values, or the raw partials
+  const double *gg_src = ctx->part_b;
+  int gg_n = g_vec;
+  if (comm) {
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_vec, 1, 0u, s_gg);
+    if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+    gg_src = s_gg; gg_n = 1;
+  }
 
   const int maxit = ctx->coarse_maxit;
   int launched = 0;
   int chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (ctx->last_coarse_iters > 8 ? ctx->last_coarse_iters - 2 : 16);
+  ctx->ev_used = 0; ctx->ev2_used = 0;
   for (;;) {
     int todo = std::min(chunk, maxit + 1 - launched);
     if (todo <= 0) todo = 1;
     for (int q = 0; q < todo; ++q, ++launched) {
-      CGDirArgs da{d, ctx->cg_g, n, ctx->st, s_gg, 1, ctx->coarse_tol, maxit};
+      CGDirArgs da{d, ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
       hipLaunchKernelGGL(cg_direction_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, da);
-      if (halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
+      if (comm && halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
       SpmvArgs a = base_args(A, d, ctx->cg_h);
       a.st = ctx->st;
       a.part_out = ctx->part_a;
+      const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
+      if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
       const int n_part_dh = launch_op<kStore, 2>(ctx, A, a);
-      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, n_part_dh, 1, 0u, s_dh);
-      if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
-      CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, s_dh, 1, ctx->part_b};
+      if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
+      const double *dh_src = ctx->part_a;
+      int dh_n = n_part_dh;
+      if (comm) {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, n_part_dh, 1, 0u, s_dh);
+        if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+        dh_src = s_dh; dh_n = 1;
+      }
+      CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
+      const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
+      if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
       hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
-      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);
-      if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+      if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+      if (comm) {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);
+        if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+      } else {
+        gg_src = ctx->part_b; gg_n = g_upd;
+      }
     }
     HIPC(hipMemcpyAsync(ctx->st_host, ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
@@ -50,6 +79,7 @@ int coarse_solve_distributed(gmg_context *ctx, double *x, const double *b, int *
     if (launched > maxit + 1) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
     chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 4;
   }
+  collect_profile_samples(ctx);
   ctx->last_coarse_iters = ctx->st_host->iters;
   ctx->stats.coarse_solves++;
   ctx->stats.coarse_iterations += ctx->st_host->iters;

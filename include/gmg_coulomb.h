@@ -156,13 +156,19 @@ typedef struct gmg_stats {
   int64_t spmv0_rows, spmv0_nnz; /* shape of the level-0 operator (for algorithmic bytes)    */
   int64_t cgupd_samples;
   double cgupd_ms_total;
+  int64_t coarse_variant;       /* 1 = fused (SpMV + direction update), 2 = unfused, of the last solve */
+  int64_t spmv0_layout;         /* 0 = CSR row windows, 1 = SELL-64 */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
 /* bracket every `sample_every`-th level-0 SpMV launch with HIP events (0 = off).           */
 int gmg_set_profiling(gmg_context *ctx, int sample_every);
-/* tuning knobs (0 keeps the default): iterations enqueued between host convergence checks,
- * use of hipGraph replay for the coarse-CG iteration chunk.                               */
+/* streaming-read and copy bandwidth of this device (GB/s) on n_bytes per array: the measured
+ * ceiling bench.py prints beside the 8 TB/s spec peak.                                    */
+int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_gbps, double *copy_gbps);
+/* tuning knobs (0 keeps the default): iterations enqueued between host convergence checks;
+ * flags bit 0: hipGraph replay of the coarse-CG chunk, bits 4-5: coarse-CG variant
+ * (0 auto by size, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration).             */
 int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph);
 
 #ifdef __cplusplus
