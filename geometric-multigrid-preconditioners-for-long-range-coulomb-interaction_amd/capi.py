@@ -291,5 +291,6 @@ class Context:
         self._chk(self.L.gmg_calibrate_hbm(self.h, C.c_int64(n_bytes), C.c_int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
 
-    def set_tuning(self, coarse_chunk=0, use_graph=0):
-        self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(use_graph)))
+    def set_tuning(self, coarse_chunk=0, use_graph=0, cg_variant=0, ssor_blocks=0):
+        flags = (use_graph & 1) | ((cg_variant & 3) << 4) | (int(ssor_blocks) << 8)
+        self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(flags)))

@@ -41,9 +41,9 @@ struct DevCSR {
 };
 
 struct SgsPlan {
-  int32_t *stage_ptr = nullptr, *stage_rows = nullptr;
-  int n_stages = 0;
-  int max_stage_rows = 0;
+  int32_t *stage_ptr = nullptr, *stage_rows = nullptr, *block_row = nullptr, *block_stage = nullptr;
+  int n_blocks = 0;
+  int n_stages_max = 0;
 };
 
 struct Level {
@@ -91,6 +91,7 @@ struct gmg_context {
   // tuning / measurement
   int coarse_chunk = 0;
   int use_graph = 0;
+  int ssor_blocks = 1;  // 1 = exact sequential SGS; B > 1 = block Jacobi of SGS (the reference on B ranks)
   int cg_variant = 0;  // 0 auto, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration
   int last_coarse_iters = 0;
   int prof_every = 0;
@@ -355,18 +356,11 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
   HIPC(hipMemsetAsync(y, 0, sizeof(double) * (size_t)L.n, ctx->stream));
   SgsArgs a{};
   a.rowptr = L.A.rowptr; a.col = L.A.col; a.val = L.A.val; a.invd = L.invd;
-  a.stage_ptr = L.sgs.stage_ptr; a.stage_rows = L.sgs.stage_rows; a.n_stages = L.sgs.n_stages;
+  a.block_row = L.sgs.block_row; a.block_stage = L.sgs.block_stage;
+  a.stage_ptr = L.sgs.stage_ptr; a.stage_rows = L.sgs.stage_rows;
   a.omega = ctx->omega; a.r = r; a.y = y;
-  if (L.n <= 65536) {
-    hipLaunchKernelGGL(sgs_sweep_single_wg_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 0);
-    hipLaunchKernelGGL(sgs_sweep_single_wg_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, 1);
-  } else {
-    const int g = std::max(1, std::min(256, (L.sgs.max_stage_rows + kThreads - 1) / kThreads));
-    for (int s = 0; s < L.sgs.n_stages; ++s)
-      hipLaunchKernelGGL(sgs_stage_kernel, dim3(g), dim3(kThreads), 0, ctx->stream, a, s);
-    for (int s = L.sgs.n_stages - 1; s >= 0; --s)
-      hipLaunchKernelGGL(sgs_stage_kernel, dim3(g), dim3(kThreads), 0, ctx->stream, a, s);
-  }
+  hipLaunchKernelGGL(sgs_sweep_kernel<false>, dim3(L.sgs.n_blocks), dim3(1024), 0, ctx->stream, a);
+  hipLaunchKernelGGL(sgs_sweep_kernel<true>, dim3(L.sgs.n_blocks), dim3(1024), 0, ctx->stream, a);
   return GMG_OK;
 }
 
@@ -645,36 +639,52 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
   return GMG_OK;
 }
 
-// SGS level schedule on the symmetrised pattern: stage(i) = 1 + max stage(j), j < i adjacent.
+// SGS level schedule on the symmetrised pattern, per block of consecutive rows:
+// stage(i) = 1 + max stage(j) over the coupled j < i of the same block.
 int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col) {
   std::vector<int64_t> trp;
   std::vector<int32_t> tcol;
   std::vector<double> tval, ones((size_t)rp[n], 1.0);
   transpose_host(n, n, rp, col, ones.data(), trp, tcol, tval);
-  std::vector<int32_t> stage((size_t)std::max<int64_t>(n, 1), 0);
-  int n_stages = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    int s = 0;
-    for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
-      if (col[k] < i) s = std::max(s, stage[(size_t)col[k]] + 1);
-    for (int64_t k = trp[(size_t)i]; k < trp[(size_t)i + 1]; ++k)
-      if (tcol[(size_t)k] < i) s = std::max(s, stage[(size_t)tcol[(size_t)k]] + 1);
-    stage[(size_t)i] = s;
-    n_stages = std::max(n_stages, s + 1);
+  const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->ssor_blocks, (n + 63) / 64));
+  std::vector<int32_t> block_row((size_t)n_blocks + 1), block_stage((size_t)n_blocks + 1, 0);
+  for (int b = 0; b <= n_blocks; ++b) block_row[(size_t)b] = (int32_t)(n * b / n_blocks);
+  std::vector<int32_t> stage((size_t)std::max<int64_t>(n, 1), 0), sp, rows((size_t)std::max<int64_t>(n, 1));
+  int n_stages_max = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
+    int ns = 0;
+    for (int64_t i = rb; i < re; ++i) {
+      int s = 0;
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+        if (col[k] < i && col[k] >= rb) s = std::max(s, stage[(size_t)col[k]] + 1);
+      for (int64_t k = trp[(size_t)i]; k < trp[(size_t)i + 1]; ++k)
+        if (tcol[(size_t)k] < i && tcol[(size_t)k] >= rb) s = std::max(s, stage[(size_t)tcol[(size_t)k]] + 1);
+      stage[(size_t)i] = s;
+      ns = std::max(ns, s + 1);
+    }
+    if (re == rb) ns = 0;
+    // this block's stage offsets (absolute positions in `rows`), appended to sp
+    std::vector<int32_t> cnt((size_t)ns + 1, 0);
+    for (int64_t i = rb; i < re; ++i) cnt[(size_t)stage[(size_t)i] + 1]++;
+    for (int t = 0; t < ns; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+    std::vector<int32_t> pos(cnt.begin(), cnt.end());
+    for (int64_t i = rb; i < re; ++i) rows[(size_t)(rb + pos[(size_t)stage[(size_t)i]]++)] = (int32_t)i;
+    for (int t = 0; t <= ns; ++t) sp.push_back((int32_t)(rb + cnt[(size_t)t]));
+    block_stage[(size_t)b + 1] = block_stage[(size_t)b] + ns;
+    n_stages_max = std::max(n_stages_max, ns);
   }
-  std::vector<int32_t> sp((size_t)n_stages + 1, 0), rows((size_t)std::max<int64_t>(n, 1));
-  for (int64_t i = 0; i < n; ++i) sp[(size_t)stage[(size_t)i] + 1]++;
-  int mx = 0;
-  for (int s = 0; s < n_stages; ++s) { mx = std::max(mx, sp[(size_t)s + 1]); sp[(size_t)s + 1] += sp[(size_t)s]; }
-  std::vector<int32_t> pos(sp.begin(), sp.end() - 1);
-  for (int64_t i = 0; i < n; ++i) rows[(size_t)pos[(size_t)stage[(size_t)i]]++] = (int32_t)i;
-  if (L.sgs.stage_ptr) (void)hipFree(L.sgs.stage_ptr);
-  if (L.sgs.stage_rows) (void)hipFree(L.sgs.stage_rows);
-  L.sgs.n_stages = n_stages; L.sgs.max_stage_rows = mx;
-  HIPC(hipMalloc(&L.sgs.stage_ptr, sizeof(int32_t) * sp.size()));
+  for (int32_t **p : {&L.sgs.stage_ptr, &L.sgs.stage_rows, &L.sgs.block_row, &L.sgs.block_stage})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  L.sgs.n_blocks = n_blocks; L.sgs.n_stages_max = n_stages_max;
+  HIPC(hipMalloc(&L.sgs.stage_ptr, sizeof(int32_t) * std::max<size_t>(sp.size(), 1)));
   HIPC(hipMalloc(&L.sgs.stage_rows, sizeof(int32_t) * rows.size()));
+  HIPC(hipMalloc(&L.sgs.block_row, sizeof(int32_t) * block_row.size()));
+  HIPC(hipMalloc(&L.sgs.block_stage, sizeof(int32_t) * block_stage.size()));
   HIPC(hipMemcpyAsync(L.sgs.stage_ptr, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(L.sgs.stage_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(L.sgs.block_row, block_row.data(), sizeof(int32_t) * block_row.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(L.sgs.block_stage, block_stage.data(), sizeof(int32_t) * block_stage.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
   return GMG_OK;
 }
@@ -730,8 +740,8 @@ int gmg_destroy(gmg_context *ctx) {
       if (p) (void)hipFree(p);
     if (L.copy_g) (void)hipFree(L.copy_g);
     if (L.copy_l) (void)hipFree(L.copy_l);
-    if (L.sgs.stage_ptr) (void)hipFree(L.sgs.stage_ptr);
-    if (L.sgs.stage_rows) (void)hipFree(L.sgs.stage_rows);
+    for (int32_t *p : {L.sgs.stage_ptr, L.sgs.stage_rows, L.sgs.block_row, L.sgs.block_stage})
+      if (p) (void)hipFree(p);
   }
   free_csr(ctx->S);
   for (double *p : {ctx->sys_full_a, ctx->sys_full_b, ctx->S_invd, ctx->S_tmp, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, ctx->cg_h, ctx->part_a, ctx->part_b, ctx->scal_dev})
@@ -1218,7 +1228,8 @@ int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph) {
   if (!ctx) return GMG_ERR_INVALID;
   ctx->coarse_chunk = coarse_chunk;
   ctx->use_graph = use_graph & 1;
-  ctx->cg_variant = (use_graph >> 4) & 3;  // bits 4-5: coarse-CG variant (0 auto, 1 fused, 2 unfused)
+  ctx->cg_variant = (use_graph >> 4) & 3;
+  if ((use_graph >> 8) > 0) ctx->ssor_blocks = use_graph >> 8;  // bits 8..: SSOR blocks (before gmg_set_level_matrix)  // bits 4-5: coarse-CG variant (0 auto, 1 fused, 2 unfused)
   return GMG_OK;
 }
 

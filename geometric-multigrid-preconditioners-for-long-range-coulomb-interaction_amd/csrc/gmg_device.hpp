@@ -587,44 +587,53 @@ __global__ __launch_bounds__(kThreads) void stream_copy_kernel(const double2 *x,
 }
 
 // ---------------------------------------------------------------- SSOR (level-scheduled SGS)
-// One workgroup sweeps the rows of its independent-set "stages" in order; rows inside a stage
-// have no mutual dependency, so the result equals the sequential Ifpack sweep in local row
-// order.  Used for levels >= 1, which are small (<= ~10^5 rows); launched as one workgroup
-// per connected chain of stages.
+// Ifpack's symmetric Gauss-Seidel is sequential in the local row order; rows without mutual
+// coupling form "stages" (computed on the host), so sweeping stage by stage reproduces the
+// sequential result exactly.  One workgroup (1024 threads = 32 half-waves) owns one block of
+// consecutive rows: with a single block this is the exact 1-rank smoother; with B blocks the
+// couplings to other blocks are dropped, which is precisely what the reference's smoother does
+// on B MPI ranks (block Jacobi of rank-local SGS).  A half-wave handles a row:
+// 32 lanes fetch val, col and y[col] in parallel (one dependent round trip instead of 27),
+// then the products are added IN CSR ORDER through shuffles -> bit-identical to the sequential sum.
 struct SgsArgs {
   const int32_t *rowptr;
   const int32_t *col;
   const double *val;
   const double *invd;
-  const int32_t *stage_ptr;   // n_stages + 1
-  const int32_t *stage_rows;  // rows ordered by stage (forward order)
-  int n_stages;
+  const int32_t *block_row;    // n_blocks + 1: row range of each block
+  const int32_t *block_stage;  // n_blocks + 1: offsets into stage_ptr (stages of each block)
+  const int32_t *stage_ptr;    // per block: (n_stages_b + 1) offsets into stage_rows, concatenated
+  const int32_t *stage_rows;   // rows ordered by (block, stage)
   double omega;
   const double *r;
   double *y;
 };
 
-// Cooperative multi-workgroup variant is not needed at these sizes: one launch per stage range.
-__global__ __launch_bounds__(kThreads) void sgs_stage_kernel(SgsArgs a, int stage) {
-  const int s = a.stage_ptr[stage], e = a.stage_ptr[stage + 1];
-  for (int q = s + blockIdx.x * kThreads + threadIdx.x; q < e; q += gridDim.x * kThreads) {
-    const int i = a.stage_rows[q];
-    double acc = 0.0;
-    for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) acc += a.val[k] * a.y[a.col[k]];
-    a.y[i] += a.omega * (a.r[i] - acc) * a.invd[i];
-  }
-}
-
-// All stages in one single-workgroup launch (small levels): __syncthreads between stages.
-__global__ __launch_bounds__(1024) void sgs_sweep_single_wg_kernel(SgsArgs a, int backward) {
-  for (int st = 0; st < a.n_stages; ++st) {
-    const int stage = backward ? a.n_stages - 1 - st : st;
-    const int s = a.stage_ptr[stage], e = a.stage_ptr[stage + 1];
-    for (int q = s + threadIdx.x; q < e; q += blockDim.x) {
+template <bool BACKWARD>
+__global__ __launch_bounds__(1024) void sgs_sweep_kernel(SgsArgs a) {
+  const int b = blockIdx.x;
+  const int rb = a.block_row[b], re = a.block_row[b + 1];
+  const int s0 = a.block_stage[b] + b, s1 = a.block_stage[b + 1] + b;  // this block's slice of stage_ptr
+  const int n_stages = s1 - s0;
+  const int hw = threadIdx.x >> 5, hl = threadIdx.x & 31;  // half-wave id, lane in it
+  for (int st = 0; st < n_stages; ++st) {
+    const int stage = BACKWARD ? n_stages - 1 - st : st;
+    const int qb = a.stage_ptr[s0 + stage], qe = a.stage_ptr[s0 + stage + 1];
+    for (int q = qb + hw; q < qe; q += 32) {
       const int i = a.stage_rows[q];
+      const int k0 = a.rowptr[i], k1 = a.rowptr[i + 1];
       double acc = 0.0;
-      for (int k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) acc += a.val[k] * a.y[a.col[k]];
-      a.y[i] += a.omega * (a.r[i] - acc) * a.invd[i];
+      for (int kb = k0; kb < k1; kb += 32) {
+        double prod = 0.0;
+        const int k = kb + hl;
+        if (k < k1) {
+          const int c = a.col[k];
+          if (c >= rb && c < re) prod = a.val[k] * a.y[c];  // other blocks' columns are dropped
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) acc += __shfl(prod, t, 32);  // in CSR order; padding adds +0.0
+      }
+      if (hl == 0) a.y[i] += a.omega * (a.r[i] - acc) * a.invd[i];
     }
     __threadfence_block();
     __syncthreads();

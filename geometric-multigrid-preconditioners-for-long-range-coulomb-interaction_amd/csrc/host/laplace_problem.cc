@@ -202,7 +202,7 @@ void ParameterReader::declare_parameters() {
             {"Polynomial degree", "1"}, {"Preconditioner", "GMG"}, {"Lammps input file", "atom_8.data"},
             // additions of this build (the reference selects the smoother by editing :969-970)
             {"Smoother", "SSOR"}, {"Smoother damping", "0.5"}, {"Smoother steps", "2"}, {"Chebyshev degree", "2"},
-            {"Device resident outer CG", "false"}};
+            {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -262,6 +262,7 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.smoother_steps = (int)prm.get_integer("Smoother steps");
   p.chebyshev_degree = (int)prm.get_integer("Chebyshev degree");
   p.device_resident_outer_cg = prm.get_bool("Device resident outer CG");
+  p.ssor_blocks = (int)prm.get_integer("SSOR blocks");
   return p;
 }
 
@@ -967,6 +968,7 @@ int LaplaceProblem<dim>::upload() {
   const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
   int rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
   if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
+  GMGC(gmg_set_tuning(gmg, 0, par.ssor_blocks << 8));  // before the level matrices: sizes the SGS schedule
   const CSRMatrix &S = system_matrix;
   if (distributed) {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),

@@ -60,6 +60,7 @@ struct Parameters {
   std::string smoother = "SSOR";  // Jacobi | SSOR | Chebyshev
   double smoother_omega = 0.5;
   int smoother_steps = 2, chebyshev_degree = 2;
+  int ssor_blocks = 1;  // 1: exact sequential SGS (mpirun=1); B: rank-local SGS on B blocks (mpirun=B)
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   static Parameters from(const ParameterReader &prm);
 };

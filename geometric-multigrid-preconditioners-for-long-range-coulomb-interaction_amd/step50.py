@@ -67,6 +67,7 @@ def prm_text(**kw) -> str:
         "smoother": ("Solver input data", "Smoother"), "omega": ("Solver input data", "Smoother damping"),
         "steps": ("Solver input data", "Smoother steps"), "cheb_degree": ("Solver input data", "Chebyshev degree"),
         "device_cg": ("Solver input data", "Device resident outer CG"),
+        "ssor_blocks": ("Solver input data", "SSOR blocks"),
     }
     sections = {}
     for k, v in kw.items():

@@ -168,7 +168,10 @@ int gmg_set_profiling(gmg_context *ctx, int sample_every);
 int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_gbps, double *copy_gbps);
 /* tuning knobs (0 keeps the default): iterations enqueued between host convergence checks;
  * flags bit 0: hipGraph replay of the coarse-CG chunk, bits 4-5: coarse-CG variant
- * (0 auto by size, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration).             */
+ * (0 auto by size, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration), bits 8..: number of
+ * SSOR blocks B (1 = exact sequential sweep; B > 1 = what the reference's smoother does on B
+ * MPI ranks: SGS inside a block of rows, couplings between blocks dropped); call before the
+ * level matrices are set.                                                                  */
 int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph);
 
 #ifdef __cplusplus

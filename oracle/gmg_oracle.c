@@ -77,7 +77,7 @@ typedef struct oracle_mg {
   csr_t S; /* system matrix */
   int has_S;
   double *S_invdiag;
-  int smoother, steps, cheb_degree;
+  int smoother, steps, cheb_degree, ssor_blocks;
   double omega, cheb_ratio, cheb_lmax_user;
   double coarse_tol;
   int coarse_maxit;
@@ -198,6 +198,7 @@ oracle_mg *oracle_mg_create(int n_levels) {
   mg->omega = 0.5;                     /* :972 */
   mg->steps = 2;                       /* :973 */
   mg->cheb_degree = 2;
+  mg->ssor_blocks = 1; /* 1 = the reference on one rank; B = block Jacobi of rank-local SGS on B ranks */
   mg->cheb_ratio = 30.0;
   mg->cheb_lmax_user = 0.0;
   mg->coarse_tol = 1e-10; /* :962 */
@@ -302,6 +303,11 @@ int oracle_mg_set_smoother(oracle_mg *mg, int kind, double omega, int steps, int
   return ORACLE_OK;
 }
 
+int oracle_mg_set_ssor_blocks(oracle_mg *mg, int n_blocks) {
+  mg->ssor_blocks = n_blocks < 1 ? 1 : n_blocks;
+  return ORACLE_OK;
+}
+
 int oracle_mg_set_coarse(oracle_mg *mg, double abs_tol, int max_it) {
   mg->coarse_tol = abs_tol; mg->coarse_maxit = max_it;
   return ORACLE_OK;
@@ -318,15 +324,25 @@ static void smoother_apply_inverse(oracle_mg *mg, int l, double *y, const double
   } else if (mg->smoother == ORACLE_SMOOTHER_SSOR) {
     v_zero(y, n);
     const csr_t *A = &L->A;
-    for (int64_t i = 0; i < n; ++i) {
-      double s = 0.0;
-      for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) s += A->val[k] * y[A->col[k]];
-      y[i] += om * (r[i] - s) * L->invdiag[i];
-    }
-    for (int64_t i = n; i-- > 0;) {
-      double s = 0.0;
-      for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) s += A->val[k] * y[A->col[k]];
-      y[i] += om * (r[i] - s) * L->invdiag[i];
+    /* Ifpack's local matrix on each rank is the diagonal block: off-rank columns are dropped.
+     * Blocks = equal runs of consecutive rows, as in gmg_coulomb.hip:setup_sgs. */
+    int nb = mg->ssor_blocks < 1 ? 1 : mg->ssor_blocks;
+    if (nb > (n + 63) / 64) nb = (int)((n + 63) / 64);
+    if (nb < 1) nb = 1;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t rb = n * b / nb, re = n * (b + 1) / nb;
+      for (int64_t i = rb; i < re; ++i) {
+        double s = 0.0;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+          if (A->col[k] >= rb && A->col[k] < re) s += A->val[k] * y[A->col[k]];
+        y[i] += om * (r[i] - s) * L->invdiag[i];
+      }
+      for (int64_t i = re; i-- > rb;) {
+        double s = 0.0;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+          if (A->col[k] >= rb && A->col[k] < re) s += A->val[k] * y[A->col[k]];
+        y[i] += om * (r[i] - s) * L->invdiag[i];
+      }
     }
   } else { /* Chebyshev on D^-1 A, Ifpack_Chebyshev recurrence, zero start */
     const double lmax = mg->cheb_lmax_user > 0 ? mg->cheb_lmax_user : L->cheb_lmax;

@@ -81,7 +81,7 @@ class OracleMG:
     """The object graph of ``LaplaceProblem::solve`` (src/step-50.cc:954-992) on the CPU."""
 
     def __init__(self, hier, smoother=SSOR, omega=0.5, steps=2, cheb_degree=2, cheb_ratio=30.0, cheb_lmax=0.0,
-                 coarse_tol=1e-10, coarse_maxit=1000):
+                 coarse_tol=1e-10, coarse_maxit=1000, ssor_blocks=1):
         L = lib()
         self.n_levels = len(hier.level_matrices)
         self.h = C.c_void_p(L.oracle_mg_create(C.c_int(self.n_levels)))
@@ -108,6 +108,7 @@ class OracleMG:
         L.oracle_mg_set_smoother(self.h, C.c_int(smoother), C.c_double(omega), C.c_int(steps), C.c_int(cheb_degree),
                                  C.c_double(cheb_ratio), C.c_double(cheb_lmax))
         L.oracle_mg_set_coarse(self.h, C.c_double(coarse_tol), C.c_int(coarse_maxit))
+        L.oracle_mg_set_ssor_blocks(self.h, C.c_int(ssor_blocks))
 
     def __del__(self):
         try:
