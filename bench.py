@@ -29,6 +29,21 @@ WORKLOADS = {
     "stress201": dict(nacl=40, box=40.0, label="3D NaCl 512k atoms (same generator), 201^3 level 0"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# context only (different hardware, 5 cycles incl. build_matrices): BASELINE.md section 1
+REFERENCE_SOLVE = {"atoms8": 2.40e6, "atoms1000": 2.06e6, "atoms8000": 1.81e6, "atoms64000": 2.31e6}
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, produced by
+    tools/gpu_pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
+    MI355X_MICROARCH.md prescribes); None when no pass exists for this kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            d = json.load(fh)
+        e = d.get(workload, {}).get(kernel)
+        return e["traffic_bytes"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def spmv_bytes(n, nnz):  # SURVEY.md 8(d)
@@ -42,7 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="atoms64000", choices=sorted(WORKLOADS))
     ap.add_argument("--smoother", default="Jacobi", choices=["Jacobi", "SSOR", "Chebyshev"])
-    ap.add_argument("--cycles", type=int, default=1, help="adaptive cycles to build; the last one is timed")
+    ap.add_argument("--cycles", type=int, default=5, help="adaptive cycles to run (the reference runs 5); the last one is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8)
     args = ap.parse_args()
@@ -83,8 +98,12 @@ def main():
         p.set_communicator(rank, world, box[0])
     t_setup = time.time()
     rep = None
+    cycles = []
     for cycle in range(args.cycles):
-        rep = p.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed)
+        rep = p.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed), marks + refines
+        cycles.append({"cycle": cycle, "dofs": rep["dofs"], "dofs_by_level": rep["dofs_by_level"],
+                       "outer_cg_iterations": rep["cg_iterations"], "coarse_cg_iterations": rep["coarse_iterations"],
+                       "solve_ms": round(rep["solve_seconds"] * 1e3, 3)})
     t_setup = time.time() - t_setup
     ctx = pkg.capi.Context.view(p.gmg_context())  # non-owning view of the problem's gmg_context (stats)
 
@@ -122,7 +141,7 @@ def main():
         kname = ("spmv_sell_kernel" if st.spmv0_layout == 1 else "spmv_tile_kernel") + ("<kStore,1>" if fused else "<kStore,2>")
         roof = {"bound": "hbm", "kernel": kname + (" (level-0 SpMV + CG direction update)" if fused else " (level-0 SpMV + d.h partials)"),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "bytes_per_launch": alg, "measured_stream_read_GBps": round(hbm_read, 1),
+                "traffic": pmc_traffic(args.workload, kname.replace("kStore,", "0, ")), "bytes_per_launch": alg, "measured_stream_read_GBps": round(hbm_read, 1),
                 "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),
                 "launches_sampled": int(st.spmv0_samples)}
         if st.cgupd_samples > 0:
@@ -139,7 +158,11 @@ def main():
             "metric": "DoF/s per CG-iter (GMG-precond Poisson, 3D)", "value": value, "unit": "DoF*it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": w["label"], "cycle": args.cycles - 1, "smoother": args.smoother,
+            "config": {"workload": w["label"] + f", adaptive cycle {args.cycles - 1} of {args.cycles}", "cycle": args.cycles - 1,
+                       "smoother": args.smoother, "cycles": cycles,
+                       "all_cycles_DoF_it_per_s": sum(c["dofs"] * c["outer_cg_iterations"] for c in cycles)
+                       / max(1e-12, sum(c["solve_ms"] for c in cycles) * 1e-3),
+                       "reference_cpu_20_ranks_DoF_it_per_s": REFERENCE_SOLVE.get(args.workload),
                        "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
                        "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
                        "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),

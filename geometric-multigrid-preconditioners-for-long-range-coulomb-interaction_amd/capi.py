@@ -20,7 +20,7 @@ UNIQUE_ID_BYTES = 128
 
 # every symbol include/gmg_coulomb.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "gmg_create", "gmg_destroy", "gmg_last_error", "gmg_synchronize",
+    "gmg_create", "gmg_destroy", "gmg_reset", "gmg_last_error", "gmg_synchronize",
     "gmg_set_system_matrix", "gmg_set_level_matrix", "gmg_set_edge_matrix", "gmg_set_prolongation",
     "gmg_set_copy_indices", "gmg_set_smoother", "gmg_set_coarse",
     "gmg_vec_alloc", "gmg_vec_free", "gmg_vec_upload", "gmg_vec_download", "gmg_vec_set_zero", "gmg_vec_equ",

@@ -689,6 +689,25 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
   return GMG_OK;
 }
 
+// frees every operator / work vector but keeps the stream, the reduction scratch and the communicator
+void release_operators(gmg_context *ctx) {
+  for (auto &L : ctx->lv) {
+    free_csr(L.A); free_csr(L.I); free_csr(L.It); free_csr(L.P); free_csr(L.Pt);
+    if (L.sol_full && L.sol_full != L.sol) (void)hipFree(L.sol_full);
+    if (L.def_full && L.def_full != L.def) (void)hipFree(L.def_full);
+    for (double *p : {L.sol, L.def, L.t, L.w1, L.w2, L.w3, L.invd})
+      if (p) (void)hipFree(p);
+    if (L.copy_g) (void)hipFree(L.copy_g);
+    if (L.copy_l) (void)hipFree(L.copy_l);
+    for (int32_t *p : {L.sgs.stage_ptr, L.sgs.stage_rows, L.sgs.block_row, L.sgs.block_stage})
+      if (p) (void)hipFree(p);
+    L = Level();
+  }
+  free_csr(ctx->S);
+  for (double **p : {&ctx->sys_full_a, &ctx->sys_full_b, &ctx->S_invd, &ctx->S_tmp, &ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
 DevCSR *which_matrix(gmg_context *ctx, int which) {
   if (which == GMG_SYSTEM) return &ctx->S;
   if (which < 0 || which >= ctx->n_levels) return nullptr;
@@ -732,19 +751,8 @@ int gmg_destroy(gmg_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   comm_destroy(ctx->comm);
-  for (auto &L : ctx->lv) {
-    free_csr(L.A); free_csr(L.I); free_csr(L.It); free_csr(L.P); free_csr(L.Pt);
-    if (L.sol_full && L.sol_full != L.sol) (void)hipFree(L.sol_full);
-    if (L.def_full && L.def_full != L.def) (void)hipFree(L.def_full);
-    for (double *p : {L.sol, L.def, L.t, L.w1, L.w2, L.w3, L.invd})
-      if (p) (void)hipFree(p);
-    if (L.copy_g) (void)hipFree(L.copy_g);
-    if (L.copy_l) (void)hipFree(L.copy_l);
-    for (int32_t *p : {L.sgs.stage_ptr, L.sgs.stage_rows, L.sgs.block_row, L.sgs.block_stage})
-      if (p) (void)hipFree(p);
-  }
-  free_csr(ctx->S);
-  for (double *p : {ctx->sys_full_a, ctx->sys_full_b, ctx->S_invd, ctx->S_tmp, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, ctx->cg_h, ctx->part_a, ctx->part_b, ctx->scal_dev})
+  release_operators(ctx);
+  for (double *p : {ctx->part_a, ctx->part_b, ctx->scal_dev})
     if (p) (void)hipFree(p);
   if (ctx->st) (void)hipFree(ctx->st);
   if (ctx->st_host) (void)hipHostFree(ctx->st_host);
@@ -753,6 +761,18 @@ int gmg_destroy(gmg_context *ctx) {
     for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return GMG_OK;
+}
+
+int gmg_reset(gmg_context *ctx, int n_levels) {
+  if (!ctx || n_levels < 1) return GMG_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  HIPC(hipStreamSynchronize(ctx->stream));
+  release_operators(ctx);
+  ctx->n_levels = n_levels;
+  ctx->lv.assign((size_t)n_levels, Level());
+  ctx->last_coarse_iters = 0;
+  ctx->stats = gmg_stats{};
   return GMG_OK;
 }
 

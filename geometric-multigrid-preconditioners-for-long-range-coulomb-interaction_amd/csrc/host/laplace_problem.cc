@@ -958,22 +958,23 @@ void LaplaceProblem<dim>::build_transfer() {
 template <int dim>
 int LaplaceProblem<dim>::upload() {
   const int L = triangulation.n_levels();
-  if (gmg) {
+  int rc = GMG_OK;
+  if (gmg) {  // next adaptive cycle: same context (stream, RCCL communicator), new operators
     for (double *p : {d_solution, d_rhs, d_full})
       if (p) gmg_vec_free(gmg, p);
     d_solution = d_rhs = d_full = nullptr;
-    gmg_destroy(gmg);
-    gmg = nullptr;
+    GMGC(gmg_reset(gmg, L));
+  } else {
+    const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
+    rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
+    if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
+    if (distributed) GMGC(gmg_comm_init(gmg, rank, n_ranks, comm_id.data()));  // once: the id is single-use
   }
-  const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
-  int rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
-  if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
   GMGC(gmg_set_tuning(gmg, 0, par.ssor_blocks << 8));  // before the level matrices: sizes the SGS schedule
   const CSRMatrix &S = system_matrix;
   if (distributed) {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),
     // levels >= 1, transfers and copy indices are replicated
-    GMGC(gmg_comm_init(gmg, rank, n_ranks, comm_id.data()));
     GMGC(gmg_set_global_sizes(gmg, S.n_rows, mg_matrices[0].n_rows));
     const LocalOperator Sl = localize(S, rank, n_ranks);
     GMGC(gmg_set_system_matrix(gmg, Sl.A.n_rows, Sl.A.n_cols, Sl.A.rowptr.data(), Sl.A.col.data(), Sl.A.val.data()));

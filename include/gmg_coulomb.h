@@ -60,6 +60,8 @@ typedef struct gmg_context gmg_context;
  * n_levels = triangulation.n_global_levels() (:709).                                      */
 int gmg_create(gmg_context **ctx, int device_id, int n_levels);
 int gmg_destroy(gmg_context *ctx);
+/* New adaptive cycle (src/step-50.cc:1484): drops every operator, keeps stream + communicator. */
+int gmg_reset(gmg_context *ctx, int n_levels);
 const char *gmg_last_error(const gmg_context *ctx);
 int gmg_synchronize(gmg_context *ctx);
 

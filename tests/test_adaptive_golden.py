@@ -19,13 +19,15 @@ from oracle import gmg_oracle as go
 KEYS11 = ("rhs_l1", "rhs_l2", "rhs_linf", "matrix_l1", "matrix_linf")
 
 
-def run_cycles(golden_dir, n_cycles, solve):
+def run_cycles(golden_dir, n_cycles, solve, communicator=False):
     S = pkg().step50
     pkg().build.build_all()
     p = S.Problem(S.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
                              cycles=n_cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0,
                              smoother="SSOR"))
     p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
+    if communicator:  # the N > 1 layout on a 1-rank RCCL communicator, kept across cycles (gmg_reset)
+        p.set_communicator(0, 1, pkg().capi.Context.unique_id())
     return p, [solve(p, c) for c in range(n_cycles)]
 
 
@@ -70,11 +72,12 @@ def test_six_adaptive_cycles_host_plus_oracle(golden, golden_dir):
 
 
 @pytest.mark.gpu
-def test_six_adaptive_cycles_on_mi355x(golden, golden_dir):
+@pytest.mark.parametrize("communicator", [False, True])
+def test_six_adaptive_cycles_on_mi355x(golden, golden_dir, communicator):
     """The same six cycles with the solve on the GPU through the C-ABI (host SolverCG over
     gmg_precondition: multi-level SSOR V-cycle with edge matrices, device-resident coarse CG)."""
     G = golden["tests/gaussian-charges.mpirun=1"]["runs"][0]["cycles"]
-    _, reps = run_cycles(golden_dir, 6, lambda p, c: p.run_cycle(c, on_device=True))
+    _, reps = run_cycles(golden_dir, 6, lambda p, c: p.run_cycle(c, on_device=True), communicator)
     assert [r["cg_iterations"] for r in reps] == [1, 6, 7, 6, 7, 7]
     for r, g in zip(reps, G):
         check_cycle(r, g)
