@@ -138,7 +138,7 @@ def main():
         fused = st.coarse_variant == 1
         alg = spmv_bytes(n0, nnz0) + (16 * n0 if fused else 0)
         ach = alg / t_k / 1e9
-        kname = ("spmv_sell_kernel" if st.spmv0_layout == 1 else "spmv_tile_kernel") + ("<kStore,1>" if fused else "<kStore,2>")
+        kname = ("spmv_sell_kernel" if st.spmv0_layout >= 1 else "spmv_tile_kernel") + ("<kStore,1>" if fused else "<kStore,2>")
         roof = {"bound": "hbm", "kernel": kname + (" (level-0 SpMV + CG direction update)" if fused else " (level-0 SpMV + d.h partials)"),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(args.workload, kname.replace("kStore,", "0, ")), "bytes_per_launch": alg, "measured_stream_read_GBps": round(hbm_read, 1),

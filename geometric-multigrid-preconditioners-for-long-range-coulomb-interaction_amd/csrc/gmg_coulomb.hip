@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "gmg_comm.hpp"
@@ -34,8 +36,11 @@ struct DevCSR {
   // SELL-64 copy (regular-width operators only), see gmg_device.hpp
   bool sell = false;
   int32_t *slice_ptr = nullptr;  // in quads
-  double2 *val2 = nullptr;
-  int4 *col4 = nullptr;
+  int32_t *slice_base = nullptr; // COL16: smallest column per slice
+  void *sell_vals = nullptr;     // uchar4 codes (VAL8) or double2 pairs
+  void *sell_cols = nullptr;     // ushort4 offsets (COL16) or int4 columns
+  double *sell_dict = nullptr;   // VAL8: 256 doubles
+  bool val8 = false, col16 = false;
   int n_slices = 0, sell_grid = 0;
   int64_t sell_quads = 0;
 };
@@ -141,8 +146,10 @@ void free_csr(DevCSR &m) {
   if (m.val) (void)hipFree(m.val);
   if (m.tile_row) (void)hipFree(m.tile_row);
   if (m.slice_ptr) (void)hipFree(m.slice_ptr);
-  if (m.val2) (void)hipFree(m.val2);
-  if (m.col4) (void)hipFree(m.col4);
+  if (m.slice_base) (void)hipFree(m.slice_base);
+  if (m.sell_vals) (void)hipFree(m.sell_vals);
+  if (m.sell_cols) (void)hipFree(m.sell_cols);
+  if (m.sell_dict) (void)hipFree(m.sell_dict);
   free_halo(m.halo);
   m = DevCSR();
 }
@@ -212,30 +219,75 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       sp[(size_t)sidx + 1] = (int32_t)quads;
     }
     if (quads * 256 <= (int64_t)(1.12 * (double)nnz) && quads * 256 < ((int64_t)1 << 31)) {
-      std::vector<double> v2((size_t)quads * 256, 0.0);
-      std::vector<int32_t> c4((size_t)quads * 256, 0);
+      // --- value dictionary (bit patterns, so -0.0 / NaN payloads survive)
+      const char *no_comp = std::getenv("GMG_DISABLE_COMPRESSION");
+      const bool allow_comp = !(no_comp && no_comp[0] == '1');
+      std::vector<double> dict;
+      std::unordered_map<uint64_t, int> code_of;
+      bool val8 = allow_comp;
+      code_of.emplace(0ull, 0);  // +0.0 is the padding value: always code 0
+      dict.push_back(0.0);
+      for (int64_t k = 0; k < nnz && val8; ++k) {
+        uint64_t bits;
+        std::memcpy(&bits, &val[k], 8);
+        if (code_of.emplace(bits, (int)dict.size()).second) {
+          dict.push_back(val[k]);
+          if (dict.size() > 256) val8 = false;
+        }
+      }
+      // --- per-slice column base, 16-bit offsets if every slice spans < 65536 columns
+      std::vector<int32_t> sbase((size_t)n_slices, 0);
+      bool col16 = allow_comp;
+      for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
+        int64_t lo = INT64_MAX, hi = -1;
+        const int64_t rend = std::min<int64_t>(n_rows, sidx * 64 + 64);
+        for (int64_t r2 = sidx * 64; r2 < rend; ++r2) {
+          lo = std::min(lo, r2 < n_cols ? r2 : lo);  // the padding column is the row itself
+          hi = std::max(hi, r2 < n_cols ? r2 : hi);
+          for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) { lo = std::min<int64_t>(lo, col[k]); hi = std::max<int64_t>(hi, col[k]); }
+        }
+        if (hi < 0) { lo = hi = 0; }
+        sbase[(size_t)sidx] = (int32_t)lo;
+        if (hi - lo > 65535) col16 = false;
+      }
+      const size_t n_ent = (size_t)quads * 256;
+      std::vector<double> v2(val8 ? 0 : n_ent, 0.0);
+      std::vector<uint8_t> v1(val8 ? n_ent : 0, 0);
+      std::vector<int32_t> c4(col16 ? 0 : n_ent, 0);
+      std::vector<uint16_t> c2(col16 ? n_ent : 0, 0);
       for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
         const int64_t q0 = sp[(size_t)sidx], nq = sp[(size_t)sidx + 1] - q0;
         for (int lane = 0; lane < 64; ++lane) {
           const int64_t r2 = sidx * 64 + lane;
           const int64_t k0 = r2 < n_rows ? rowptr[r2] : 0, len = r2 < n_rows ? rowptr[r2 + 1] - k0 : 0;
-          const int32_t padcol = r2 < std::min(n_rows, n_cols) ? (int32_t)r2 : 0;
+          const int32_t padcol = r2 < std::min(n_rows, n_cols) ? (int32_t)r2 : sbase[(size_t)sidx];
           for (int64_t j = 0; j < 4 * nq; ++j) {
             const int64_t qq = q0 + j / 4, e = j & 3;
-            const size_t ov = (size_t)(((2 * qq + (e >> 1)) * 64 + lane) * 2 + (e & 1));
-            const size_t oc = (size_t)((qq * 64 + lane) * 4 + e);
-            if (j < len) { v2[ov] = val[k0 + j]; c4[oc] = debug_nogather ? padcol : col[k0 + j]; }
-            else { v2[ov] = 0.0; c4[oc] = padcol; }
+            const size_t ov = (size_t)(((2 * qq + (e >> 1)) * 64 + lane) * 2 + (e & 1));  // double2-pair layout
+            const size_t oc = (size_t)((qq * 64 + lane) * 4 + e);                          // 4-per-lane layout
+            const int32_t cj = (j < len && !debug_nogather) ? col[k0 + j] : padcol;
+            const double vj = j < len ? val[k0 + j] : 0.0;
+            if (val8) { uint64_t bits; std::memcpy(&bits, &vj, 8); v1[oc] = (uint8_t)code_of.at(bits); }
+            else v2[ov] = vj;
+            if (col16) c2[oc] = (uint16_t)(cj - sbase[(size_t)sidx]);
+            else c4[oc] = cj;
           }
         }
       }
+      dict.resize(256, 0.0);
       HIPC(hipMalloc(&m.slice_ptr, sizeof(int32_t) * sp.size()));
-      HIPC(hipMalloc(&m.val2, sizeof(double) * v2.size()));
-      HIPC(hipMalloc(&m.col4, sizeof(int32_t) * c4.size()));
+      HIPC(hipMalloc(&m.slice_base, sizeof(int32_t) * sbase.size()));
+      HIPC(hipMalloc(&m.sell_dict, sizeof(double) * 256));
+      const size_t vbytes = val8 ? v1.size() : v2.size() * 8, cbytes = col16 ? c2.size() * 2 : c4.size() * 4;
+      HIPC(hipMalloc(&m.sell_vals, vbytes + 64));
+      HIPC(hipMalloc(&m.sell_cols, cbytes + 64));
       HIPC(hipMemcpyAsync(m.slice_ptr, sp.data(), sizeof(int32_t) * sp.size(), hipMemcpyHostToDevice, ctx->stream));
-      HIPC(hipMemcpyAsync(m.val2, v2.data(), sizeof(double) * v2.size(), hipMemcpyHostToDevice, ctx->stream));
-      HIPC(hipMemcpyAsync(m.col4, c4.data(), sizeof(int32_t) * c4.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.slice_base, sbase.data(), sizeof(int32_t) * sbase.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.sell_dict, dict.data(), sizeof(double) * 256, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.sell_vals, val8 ? (const void *)v1.data() : (const void *)v2.data(), vbytes, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.sell_cols, col16 ? (const void *)c2.data() : (const void *)c4.data(), cbytes, hipMemcpyHostToDevice, ctx->stream));
       HIPC(hipStreamSynchronize(ctx->stream));
+      m.val8 = val8; m.col16 = col16;
       m.sell = true;
       m.n_slices = (int)n_slices;
       m.sell_quads = quads;
@@ -283,8 +335,11 @@ int alloc_vec(gmg_context *ctx, double **p, int64_t n) {
 template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
-    SellArgs sa{m.slice_ptr, m.val2, m.col4, m.n_slices, (int)m.n_rows, a};
-    hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.n_slices, (int)m.n_rows, a};
+    if (m.val8 && m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    else if (m.val8) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    else if (m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
     return m.sell_grid;
   }
   hipLaunchKernelGGL((spmv_tile_kernel<MODE, CG>), dim3(m.grid), dim3(kThreads), 0, ctx->stream, a);
@@ -829,7 +884,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
     ctx->stats.spmv0_rows = n_rows;
     ctx->stats.spmv0_nnz = rowptr[n_rows];
-    ctx->stats.spmv0_layout = L.A.sell ? 1 : 0;
+    ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) : 0;
     ctx->last_coarse_iters = 0;
   }
   HIPC(hipStreamSynchronize(ctx->stream));

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace gmg {
 
 constexpr int kThreads = 256;      // 4 waves
@@ -286,18 +288,36 @@ __global__ __launch_bounds__(kThreads) void spmv_tile_kernel(SpmvArgs a) {
 // as one software-pipelined loop (two quads = 6 KB per wave prefetched ahead, across slice
 // boundaries): no LDS, no barriers, no pipeline refill per slice.  Chosen at upload when the
 // padding costs < 12 %.
+// Compression of the two streams (decided per operator at upload, values stay bit-exact):
+//   VAL8  : the operator has <= 256 distinct values (FE matrices on uniform / 2:1 meshes have a
+//           handful) -> one byte per entry indexing a dictionary that the kernel keeps in LDS
+//   COL16 : every slice's columns lie within 65536 of the slice's smallest column -> 16-bit
+//           offsets from a per-slice base (lattice operators up to ~180^3)
+// so the level-0 lattice streams 3 bytes per nonzero instead of 12.
 struct SellArgs {
-  const int32_t *qptr;  // n_slices + 1, in quads
-  const double2 *val2;
-  const int4 *col4;
+  const int32_t *qptr;   // n_slices + 1, in quads
+  const int32_t *sbase;  // COL16: smallest column of each slice
+  const void *vals;      // VAL8: uchar4[quads * 64]        else double2[2 * quads * 64]
+  const void *cols;      // COL16: ushort4[quads * 64]      else int4[quads * 64]
+  const double *dict;    // VAL8: 256 doubles
   int n_slices;
   int n_rows;
   SpmvArgs a;  // vectors, epilogue operands, CG state (rowptr/col/val unused)
 };
 
-template <int MODE, int CG>
+template <bool VAL8>
+struct SellVals {  // the 4 values of one quad as loaded (codes or doubles)
+  double2 v0, v1;
+};
+template <>
+struct SellVals<true> {
+  uchar4 code;
+};
+
+template <int MODE, int CG, bool VAL8, bool COL16>
 __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
   __shared__ double red[4];
+  __shared__ double dict[VAL8 ? 256 : 1];
   const SpmvArgs &a = sa.a;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   constexpr bool XFORM = (CG == 1);
@@ -308,13 +328,18 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
   if constexpr (CG == 2) {
     if (a.st->done) return;
   }
+  if constexpr (VAL8) {
+    dict[threadIdx.x] = sa.dict[threadIdx.x];
+    __syncthreads();
+  }
   // XCD-aware contiguous ownership: XCD -> eighth of the slices, wave -> contiguous run in it
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
   const int per_xcd = (sa.n_slices + 7) >> 3;
   const int x0 = xcd * per_xcd, x1 = min(x0 + per_xcd, sa.n_slices);
   const int waves = nb * 4;
   const int per_wave = (max(x1 - x0, 0) + waves - 1) / waves;
-  const int s0 = x0 + (lb * 4 + wid) * per_wave, s1 = min(s0 + per_wave, x1);
+  const int s0 = __builtin_amdgcn_readfirstlane(x0 + (lb * 4 + wid) * per_wave);
+  const int s1 = __builtin_amdgcn_readfirstlane(min(s0 + per_wave, x1));
   double dot_acc = 0.0;
 
   auto X = [&](int c) -> double {
@@ -327,20 +352,20 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
     int q = sa.qptr[s0];
     int s = s0;
     int qe = sa.qptr[s0 + 1];  // end of the current slice
+    int base = COL16 ? sa.sbase[s0] : 0;
     double acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
-    const double2 *vbase = sa.val2 + lane;
-    const int4 *cbase = sa.col4 + lane;
-    double2 va0, va1, vb0, vb1, vc0, vc1;
-    int4 ca, cb, cc;
-    va0 = va1 = vb0 = vb1 = vc0 = vc1 = double2{0.0, 0.0};
-    ca = cb = cc = int4{0, 0, 0, 0};
+    using ColT = typename std::conditional<COL16, ushort4, int4>::type;
+    const ColT *cbase = reinterpret_cast<const ColT *>(sa.cols) + lane;
+    const double2 *vbase = reinterpret_cast<const double2 *>(sa.vals) + lane;
+    const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
+    SellVals<VAL8> va{}, vb{}, vc{};
+    ColT ca{}, cb{}, cc{};
 
-#define GMG_LOADQ(V0, V1, C, Q)                       \
-  {                                                   \
-    C = cbase[(size_t)(Q) * 64];                      \
-    V0 = vbase[(size_t)(2 * (Q)) * 64];               \
-    V1 = vbase[(size_t)(2 * (Q) + 1) * 64];           \
-  }
+    auto load_quad = [&](SellVals<VAL8> &V, ColT &C, int Q) {
+      C = cbase[(size_t)Q * 64];
+      if constexpr (VAL8) V.code = kbase[(size_t)Q * 64];
+      else { V.v0 = vbase[(size_t)(2 * Q) * 64]; V.v1 = vbase[(size_t)(2 * Q + 1) * 64]; }
+    };
     auto finish_slice = [&]() {
       const int r = s * 64 + lane;
       if (r < sa.n_rows) {
@@ -361,32 +386,32 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
       ++s;
       if (s < s1) {
         qe = sa.qptr[s + 1];
+        if constexpr (COL16) base = sa.sbase[s];
         acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
       }
     };
-    // gathers of the current quad first, THEN the prefetch two quads ahead: the in-order
-    // vmcnt wait for the gathers leaves the younger stream loads in flight
-#define GMG_STEP(V0, V1, C, NV0, NV1, NC)                              \
-  {                                                                    \
-    const double x0_ = X(C.x), x1_ = X(C.y), x2_ = X(C.z), x3_ = X(C.w); \
-    if (q + 2 < Q1) GMG_LOADQ(NV0, NV1, NC, q + 2);                    \
-    acc += V0.x * x0_; acc += V0.y * x1_; acc += V1.x * x2_; acc += V1.y * x3_; \
-    ++q;                                                               \
-    while (q == qe && s < s1) finish_slice();                          \
-  }
-    GMG_LOADQ(va0, va1, ca, q);
-    if (q + 1 < Q1) GMG_LOADQ(vb0, vb1, cb, q + 1);
-    // empty leading slices (width 0) cannot occur: every row has a diagonal entry; guard anyway
-    while (q == qe && s < s1) finish_slice();
+    // gathers of the current quad first, THEN the prefetch two quads ahead: the in-order vmcnt
+    // wait for the gathers leaves the younger stream loads in flight
+    auto step = [&](SellVals<VAL8> &V, ColT &C, SellVals<VAL8> &NV, ColT &NC) {
+      const double x0_ = X(base + (int)C.x), x1_ = X(base + (int)C.y), x2_ = X(base + (int)C.z), x3_ = X(base + (int)C.w);
+      double w0, w1, w2, w3;
+      if constexpr (VAL8) { w0 = dict[V.code.x]; w1 = dict[V.code.y]; w2 = dict[V.code.z]; w3 = dict[V.code.w]; }
+      else { w0 = V.v0.x; w1 = V.v0.y; w2 = V.v1.x; w3 = V.v1.y; }
+      if (q + 2 < Q1) load_quad(NV, NC, q + 2);
+      acc += w0 * x0_; acc += w1 * x1_; acc += w2 * x2_; acc += w3 * x3_;
+      ++q;
+      while (q == qe && s < s1) finish_slice();
+    };
+    load_quad(va, ca, q);
+    if (q + 1 < Q1) load_quad(vb, cb, q + 1);
+    while (q == qe && s < s1) finish_slice();  // (empty slices cannot occur: every row has a diagonal)
     while (q < Q1) {
-      GMG_STEP(va0, va1, ca, vc0, vc1, cc);
+      step(va, ca, vc, cc);
       if (q >= Q1) break;
-      GMG_STEP(vb0, vb1, cb, va0, va1, ca);
+      step(vb, cb, va, ca);
       if (q >= Q1) break;
-      GMG_STEP(vc0, vc1, cc, vb0, vb1, cb);
+      step(vc, cc, vb, cb);
     }
-#undef GMG_STEP
-#undef GMG_LOADQ
   }
   if constexpr (CG != 0) {
     const double sblock = block_sum(dot_acc, red);

@@ -159,7 +159,7 @@ typedef struct gmg_stats {
   int64_t cgupd_samples;
   double cgupd_ms_total;
   int64_t coarse_variant;       /* 1 = fused (SpMV + direction update), 2 = unfused, of the last solve */
-  int64_t spmv0_layout;         /* 0 = CSR row windows, 1 = SELL-64 */
+  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
