@@ -133,6 +133,8 @@ int fail(gmg_context *ctx, int code, const char *msg) {
   return code;
 }
 
+constexpr int64_t kTileMaxRowsEarly = 1024;
+
 inline int grid_for(int64_t n) {
   int64_t g = (n + kThreads - 1) / kThreads;
   if (g < 1) g = 1;
@@ -180,7 +182,9 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   while (r < n_rows) {
     const int64_t ka = rowptr[r] & ~(int64_t)3;
     int64_t e = r + 1;  // a tile always holds at least one row (possibly a "long row")
-    while (e < n_rows && rowptr[e + 1] - ka <= kTileNnz) ++e;
+    // rows are capped too: operators with long runs of empty rows (P^T onto the level-0 lattice)
+    // would otherwise put 10^5 rows into one workgroup
+    while (e < n_rows && rowptr[e + 1] - ka <= kTileNnz && e - r < kTileMaxRowsEarly) ++e;
     if (rowptr[e] - ka > kTileNnz) e = r + 1;
     tiles.push_back((int32_t)e);
     r = e;
@@ -300,6 +304,9 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       }
     }
   }
+  if (std::getenv("GMG_DEBUG_UPLOAD"))
+    std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d\n", (long long)n_rows,
+                 (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid);
   return GMG_OK;
 }
 
@@ -514,7 +521,9 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   Level &L0 = ctx->lv[0];
   const DevCSR &A = L0.A;
   if (!A.valid) return fail(ctx, GMG_ERR_INVALID, "level-0 matrix not set");
-  if (ctx->dist || (ctx->cg_variant == 0 && L0.n >= kUnfusedMinRowsDecl) || ctx->cg_variant == 2)
+  int variant = ctx->cg_variant;
+  if (const char *ev = std::getenv("GMG_CG_VARIANT")) variant = std::atoi(ev);  // tuning experiments
+  if (ctx->dist || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2)
   {
     ctx->stats.coarse_variant = 2;
     return coarse_solve_unfused(ctx, x, b, iters_out, res_out);
