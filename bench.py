@@ -71,7 +71,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ  # under torch.distributed.run: use the one-process-per-GPU layout even for N = 1
+    if launched:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -81,7 +82,7 @@ def main():
     w = WORKLOADS[args.workload]
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -91,7 +92,7 @@ def main():
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
                              quad_rhs=1, global_refinement=0, smoother=args.smoother))
     p.set_nacl_atoms(w["nacl"])
-    if world > 1:
+    if launched:
         # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
         box = [pkg.capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
@@ -120,7 +121,7 @@ def main():
     st = ctx.stats()
     ctx.set_profiling(0)
     hbm_read, hbm_copy = ctx.calibrate_hbm(1 << 30, 10) if rank == 0 else (0.0, 0.0)
-    if world > 1:
+    if launched:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -183,7 +184,8 @@ def main():
         }
         print(json.dumps(out))
     p.close()
-    if world > 1:
+    if launched:
+        dist.barrier()
         dist.destroy_process_group()
 
 

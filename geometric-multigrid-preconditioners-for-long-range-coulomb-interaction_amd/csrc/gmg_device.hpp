@@ -22,7 +22,6 @@ namespace gmg {
 
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kTileNnz = 4096;     // LDS row window, doubles (32 KiB) -> 4 workgroups / CU
-constexpr int kTileCap = 4092;     // max nnz of a regular tile (window start is rounded down to 4)
 constexpr int kPasses = kTileNnz / (kThreads * 4);
 constexpr int kMaxPartials = 2048; // upper bound of any grid that emits reduction partials
 

@@ -1,0 +1,169 @@
+"""Edge cases of the device layouts behind gmg_spmv (all compared bit-exactly with the oracle):
+SELL-64 with and without each compression, the CSR row-window kernel incl. its long-row path,
+empty rows, row counts that are not multiples of 64, rectangular operators; plus
+size-independent properties of the full-size BASELINE operator (121^3 level 0)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from gpu_util import capi, pkg
+from oracle import gmg_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def csr(n_rows, n_cols, rows):
+    """rows: list of (cols, vals) per row"""
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    col, val = [], []
+    for i, (c, v) in enumerate(rows):
+        col += list(c)
+        val += list(v)
+        rp[i + 1] = len(col)
+    return SimpleNamespace(n_rows=n_rows, n_cols=n_cols, rowptr=rp, col=np.array(col, dtype=np.int32),
+                           val=np.array(val, dtype=np.float64), nnz=len(col))
+
+
+def apply_level0(m, x):
+    c = capi().Context(1)
+    c.set_level_matrix(0, m)
+    vx, vy = c.vector(m.n_cols, x), c.vector(m.n_rows)
+    c.spmv(0, vy, vx)
+    y = vy.download()
+    lay = int(c.stats().spmv0_layout)
+    c.close()
+    return y, lay
+
+
+def banded(n, width, rng, distinct=None, spread=1):
+    rows = []
+    for i in range(n):
+        c = sorted({min(n - 1, max(0, i + spread * (k - width // 2))) for k in range(width)} | {i})
+        v = rng.standard_normal(len(c)) if distinct is None else rng.choice(distinct, len(c))
+        v[c.index(i)] = 4.0 + abs(v[c.index(i)])
+        rows.append((c, v))
+    return csr(n, n, rows)
+
+
+@pytest.mark.parametrize("case,expect", [
+    ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
+])
+def test_sell_variants_bit_exact(case, expect):
+    rng = np.random.default_rng(11)
+    n = 5000 + 37  # not a multiple of 64
+    distinct = np.array([-1 / 6, -1 / 12, 8 / 3, 0.0, 1.25]) if "val8" in case else None
+    spread = 1 if "col16" in case else 3000  # 27 * 3000 > 65535 columns within a slice
+    m = banded(n if spread == 1 else 200000, 27, rng, distinct, spread)
+    x = rng.standard_normal(m.n_cols)
+    y, lay = apply_level0(m, x)
+    assert lay == expect, (case, lay)
+    assert np.array_equal(y, go.spmv(m, x))
+
+
+def test_more_than_256_values_falls_back_to_fp64_values():
+    rng = np.random.default_rng(12)
+    m = banded(3000, 27, rng)  # random values: thousands of distinct doubles
+    x = rng.standard_normal(3000)
+    y, lay = apply_level0(m, x)
+    assert lay == 1 + 4  # SELL-64, fp64 values, 16-bit columns
+    assert np.array_equal(y, go.spmv(m, x))
+    m9 = banded(3000, 9, rng)  # 9 -> 12 entries per row would be 33 % padding: stays CSR
+    y, lay = apply_level0(m9, x)
+    assert lay == 0 and np.array_equal(y, go.spmv(m9, x))
+
+
+def test_csr_window_irregular_empty_and_long_rows():
+    rng = np.random.default_rng(13)
+    n = 3000
+    rows = []
+    for i in range(n):
+        k = [0, 1, 3, 40, 9][i % 5] if i != 1234 else 6000  # empty rows, ragged rows, one row wider than the LDS window
+        c = np.sort(rng.choice(n if k < 3000 else 20000, size=k, replace=False)) if k else []
+        rows.append((c, rng.standard_normal(k)))
+    m = csr(n, 20000, rows)
+    x = rng.standard_normal(20000)
+    c = capi().Context(2)
+    c.set_level_matrix(0, banded(2048, 3, rng))
+    c.set_level_matrix(1, banded(n, 3, rng))
+    c.set_prolongation(0, csr(n, 2048, [(cc[cc < 2048][:50], vv[:len(cc[cc < 2048][:50])]) for cc, vv in
+                                        ((np.asarray(r[0], dtype=np.int64), np.asarray(r[1])) for r in rows)]))
+    P = csr(n, 2048, [(cc[cc < 2048][:50], vv[:len(cc[cc < 2048][:50])]) for cc, vv in
+                      ((np.asarray(r[0], dtype=np.int64), np.asarray(r[1])) for r in rows)])
+    xc = rng.standard_normal(2048)
+    vf, vc = c.vector(n), c.vector(2048, xc)
+    c.prolongate(0, vf, vc)
+    assert np.array_equal(vf.download(), go.spmv(P, xc))
+    f, c0 = rng.standard_normal(n), rng.standard_normal(2048)
+    vf.upload(f); vc.upload(c0)
+    c.restrict_and_add(0, vc, vf)
+    assert np.array_equal(vc.download(), go.spmv_transpose(P, f, c0))
+    c.close()
+    # the long row (6000 nnz > 4096-entry window) goes through the strided path: tolerance, not bit-exact
+    y, lay = apply_level0(m, x)
+    ref = go.spmv(m, x)
+    assert lay == 0
+    mask = np.ones(n, dtype=bool); mask[1234] = False
+    assert np.array_equal(y[mask], ref[mask])
+    assert abs(y[1234] - ref[1234]) <= 1e-12 * np.abs(m.val[m.rowptr[1234]:m.rowptr[1235]]).sum() * np.abs(x).max()
+
+
+def test_invalid_operator_is_rejected():
+    c = capi().Context(1)
+    bad = csr(4, 4, [([0], [1.0]), ([7], [1.0]), ([2], [1.0]), ([3], [1.0])])  # column out of range
+    with pytest.raises(capi().GMGError) as e:
+        c.set_level_matrix(0, bad)
+    assert e.value.code == capi().ERR_INVALID
+    with pytest.raises(capi().GMGError):
+        c.spmv(0, c.vector(4), c.vector(4))  # operator not set
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE config 5, cycle 0: 121^3 level 0 (1 771 561 rows, 47 045 881 nnz) on the host."""
+    S = pkg().step50
+    p = S.Problem(S.prm_text(left=0, right=20, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+                             cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi"))
+    p.set_nacl_atoms(20)
+    rep = p.run_cycle(0, on_device=True)
+    return p, rep
+
+
+def test_full_size_cycle0_matches_cluster_log(golden, full_size):
+    """SSOR_64k_atoms.o876224:14-22 -- every printed digit, at the reference's largest size."""
+    from conftest import rel_close
+
+    p, r = full_size
+    g = golden["cluster/SSOR_64k_atoms"]["runs"][0]["cycles"][0]
+    assert r["active_cells"] == g["active_cells"] and r["dofs_by_level"] == g["dofs_by_level"]
+    assert r["cg_iterations"] == g["cg_iterations"] == 1
+    assert abs(r["starting_value"] - g["starting_value"]) < 0.6e-6
+    assert abs(r["convergence_value"] - g["convergence_value"]) <= 1e-4 * g["convergence_value"]
+    for k in ("sol_l1", "sol_l2", "sol_linf"):
+        assert rel_close(r[k], g[k], 11), k
+
+
+def test_full_size_operator_properties(full_size):
+    """Size-independent properties of the 121^3 operator on the GPU: linearity, symmetry,
+    and the residual of the solve recomputed independently."""
+    p, rep = full_size
+    ctx = capi().Context.view(p.gmg_context())
+    n = rep["dofs"]
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    va, vb, vab = ctx.vector(n, a), ctx.vector(n, b), ctx.vector(n, 2.0 * a - 3.0 * b)
+    ya, yb, yab = ctx.vector(n), ctx.vector(n), ctx.vector(n)
+    for which in (0, capi().SYSTEM):
+        ctx.spmv(which, ya, va); ctx.spmv(which, yb, vb); ctx.spmv(which, yab, vab)
+        A_a, A_b, A_ab = ya.download(), yb.download(), yab.download()
+        scale = np.abs(A_a).max() + np.abs(A_b).max()
+        assert np.abs(A_ab - (2.0 * A_a - 3.0 * A_b)).max() <= 1e-13 * scale * 10          # linearity
+        assert abs(ctx.dot(vb, ya) - ctx.dot(va, yb)) <= 1e-11 * abs(ctx.dot(va, ya))        # symmetry
+    # residual of the converged solve: |b - A x| <= 1e-8 |b| recomputed with numpy on the host
+    h = p.hierarchy()
+    x = np.where(h.constrained, 0.0, p.vector("solution"))
+    vx, vr = ctx.vector(n, x), ctx.vector(n)
+    ctx.spmv(capi().SYSTEM, vr, vx)
+    res = np.linalg.norm(h.system_rhs - vr.download())
+    assert res <= 1.05e-8 * np.linalg.norm(h.system_rhs)
