@@ -1193,6 +1193,78 @@ int gmg_cg_solve(gmg_context *ctx, double *x, const double *b, double rel_tol, i
   return rc;
 }
 
+// ---- N1: charge density ----
+
+int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo, const double *cell_h,
+                       const double *root_lo, double root_h, int64_t n_atoms, const double *atom_xyz,
+                       const double *atom_q, double r_c, double cutoff, int use_lists, int nq,
+                       const double *quadrature_points, double *dens) {
+  if (!ctx || n_cells < 0 || n_atoms < 0 || nq < 1 || n_cells >= ((int64_t)1 << 31)) return GMG_ERR_INVALID;
+  if (n_cells == 0) return GMG_OK;
+  (void)hipSetDevice(ctx->device);
+  // bins of edge `cutoff` over the atoms' bounding box (host; 64 k atoms: microseconds)
+  DensityArgs a{};
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int d = 0; d < 3; ++d) { lo[d] = 1e300; hi[d] = -1e300; }
+  for (int64_t i = 0; i < n_atoms; ++i)
+    for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], atom_xyz[3 * i + d]); hi[d] = std::max(hi[d], atom_xyz[3 * i + d]); }
+  if (n_atoms == 0) { for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0; }
+  const double bs = std::max(cutoff, 1e-12);
+  int bn[3];
+  int64_t total = 1;
+  for (int d = 0; d < 3; ++d) { bn[d] = std::max(1, (int)std::floor((hi[d] - lo[d]) / bs) + 1); total *= bn[d]; }
+  if (total > ((int64_t)1 << 28)) return fail(ctx, GMG_ERR_UNSUPPORTED, "atom bin grid too large");
+  std::vector<int32_t> bptr((size_t)total + 1, 0), bitems((size_t)std::max<int64_t>(n_atoms, 1));
+  auto bin_of = [&](int64_t i) {
+    int b[3];
+    for (int d = 0; d < 3; ++d) b[d] = std::min(bn[d] - 1, std::max(0, (int)std::floor((atom_xyz[3 * i + d] - lo[d]) / bs)));
+    return (int64_t)b[0] + bn[0] * ((int64_t)b[1] + (int64_t)bn[1] * b[2]);
+  };
+  for (int64_t i = 0; i < n_atoms; ++i) bptr[(size_t)bin_of(i) + 1]++;
+  for (int64_t b = 0; b < total; ++b) bptr[(size_t)b + 1] += bptr[(size_t)b];
+  {
+    std::vector<int32_t> pos(bptr.begin(), bptr.end() - 1);
+    for (int64_t i = 0; i < n_atoms; ++i) bitems[(size_t)pos[(size_t)bin_of(i)]++] = (int32_t)i;
+  }
+  double *d_lo = nullptr, *d_h = nullptr, *d_root = nullptr, *d_xyz = nullptr, *d_q = nullptr, *d_qp = nullptr, *d_dens = nullptr;
+  int32_t *d_bptr = nullptr, *d_bitems = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)d_lo, (void *)d_h, (void *)d_root, (void *)d_xyz, (void *)d_q, (void *)d_qp, (void *)d_dens, (void *)d_bptr, (void *)d_bitems})
+      if (p) (void)hipFree(p);
+  };
+#define UP(dst, src, bytes)                                                                   \
+  do {                                                                                        \
+    if (hipMalloc(&dst, std::max<size_t>((bytes), 8)) != hipSuccess ||                         \
+        ((bytes) && hipMemcpyAsync(dst, src, (bytes), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) { \
+      cleanup();                                                                              \
+      return fail(ctx, GMG_ERR_HIP, "gmg_charge_density: upload failed");                     \
+    }                                                                                         \
+  } while (0)
+  UP(d_lo, cell_lo, sizeof(double) * 3 * (size_t)n_cells);
+  UP(d_h, cell_h, sizeof(double) * (size_t)n_cells);
+  UP(d_root, root_lo, sizeof(double) * 3 * (size_t)n_cells);
+  UP(d_xyz, atom_xyz, sizeof(double) * 3 * (size_t)n_atoms);
+  UP(d_q, atom_q, sizeof(double) * (size_t)n_atoms);
+  UP(d_qp, quadrature_points, sizeof(double) * 3 * (size_t)nq);
+  UP(d_bptr, bptr.data(), sizeof(int32_t) * bptr.size());
+  UP(d_bitems, bitems.data(), sizeof(int32_t) * bitems.size());
+#undef UP
+  if (hipMalloc(&d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq) != hipSuccess) { cleanup(); return fail(ctx, GMG_ERR_HIP, "gmg_charge_density: out of memory"); }
+  a.cell_lo = d_lo; a.cell_h = d_h; a.root_lo = d_root; a.root_h = root_h;
+  a.atom_xyz = d_xyz; a.atom_q = d_q; a.n_atoms = (int)n_atoms;
+  a.bin_lo0 = lo[0]; a.bin_lo1 = lo[1]; a.bin_lo2 = lo[2]; a.bin_size = bs;
+  a.bin_n0 = bn[0]; a.bin_n1 = bn[1]; a.bin_n2 = bn[2];
+  a.bin_ptr = d_bptr; a.bin_items = d_bitems;
+  a.cutoff = cutoff; a.r_c = r_c; a.use_lists = use_lists;
+  a.qp = d_qp; a.nq = nq; a.n_cells = (int)n_cells; a.dens = d_dens;
+  hipLaunchKernelGGL(charge_density_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(kThreads), 0, ctx->stream, a);
+  hipError_t e = hipMemcpyAsync(dens, d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) { ctx->err = std::string("gmg_charge_density: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
+  return GMG_OK;
+}
+
 // ---- distributed ----
 
 int gmg_comm_unique_id(void *out_id) { return comm_unique_id(out_id) ? GMG_ERR_COMM : GMG_OK; }

@@ -593,6 +593,104 @@ __global__ __launch_bounds__(kThreads) void reduce_final_kernel(const double *pa
   }
 }
 
+// ---------------------------------------------------------------- Gaussian charge density
+// rho(x_q) = 4 pi / (r_c^3 pi^1.5) sum_k q_k exp(-|x_q - x_k|^2 / r_c^2) at the quadrature points of
+// every active cell (reference: src/step-50.cc:509-575), the sum running over the atoms whose
+// distance to ANY vertex of the cell's ROOT cell is below cutoff (the reference's per-cell atom
+// lists, :260-306, inherited unchanged by children, :441-450) or over all atoms.  One wavefront
+// per cell: lanes stride over the candidate atoms of the neighbouring bins, evaluate the same
+// predicate (nearest root-cell vertex, direction by direction), accumulate up to 8 quadrature
+// points at a time in registers and combine with a shuffle reduction.
+struct DensityArgs {
+  const double *cell_lo;    // [n_cells * 3] lower corner of the cell
+  const double *cell_h;     // [n_cells]
+  const double *root_lo;    // [n_cells * 3] lower corner of the cell's root cell
+  double root_h;
+  const double *atom_xyz;   // [n_atoms * 3]
+  const double *atom_q;
+  int n_atoms;
+  double bin_lo0, bin_lo1, bin_lo2, bin_size;
+  int bin_n0, bin_n1, bin_n2;
+  const int32_t *bin_ptr;
+  const int32_t *bin_items;
+  double cutoff, r_c;
+  int use_lists;
+  const double *qp;         // [nq * 3] quadrature points on the unit cell
+  int nq, n_cells;
+  double *dens;             // [n_cells * nq]
+};
+
+__global__ __launch_bounds__(kThreads) void charge_density_kernel(DensityArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= a.n_cells) return;
+  const double constant_value = 4.0 * M_PI / (a.r_c * a.r_c * a.r_c * pow(M_PI, 1.5));
+  const double inv = 1.0 / (a.r_c * a.r_c);
+  double lo[3], rlo[3], rhi[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = a.cell_lo[3 * (size_t)cell + d];
+    rlo[d] = a.root_lo[3 * (size_t)cell + d];
+    rhi[d] = rlo[d] + a.root_h;
+  }
+  const double h = a.cell_h[cell];
+  int b0[3] = {0, 0, 0}, b1[3] = {0, 0, 0};
+  const double blo[3] = {a.bin_lo0, a.bin_lo1, a.bin_lo2};
+  const int bn[3] = {a.bin_n0, a.bin_n1, a.bin_n2};
+  if (a.use_lists) {
+    for (int d = 0; d < 3; ++d) {
+      b0[d] = max((int)floor((rlo[d] - a.cutoff - blo[d]) / a.bin_size), 0);
+      b1[d] = min((int)floor((rhi[d] + a.cutoff - blo[d]) / a.bin_size), bn[d] - 1);
+    }
+  }
+  for (int qb = 0; qb < a.nq; qb += 8) {
+    const int nqb = min(8, a.nq - qb);
+    double xq[8][3], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j] = 0.0;
+      for (int d = 0; d < 3; ++d) xq[j][d] = j < nqb ? lo[d] + h * a.qp[3 * (qb + j) + d] : 0.0;
+    }
+    auto add_atom = [&](int k) {
+      const double ax = a.atom_xyz[3 * (size_t)k], ay = a.atom_xyz[3 * (size_t)k + 1], az = a.atom_xyz[3 * (size_t)k + 2];
+      if (a.use_lists) {
+        const double at[3] = {ax, ay, az};
+        double d2 = 0.0;
+        for (int d = 0; d < 3; ++d) {
+          const double dl = at[d] - rlo[d], dh = at[d] - rhi[d];
+          const double m = fabs(dl) <= fabs(dh) ? dl : dh;
+          d2 += m * m;
+        }
+        if (!(sqrt(d2) < a.cutoff)) return;
+      }
+      const double qk = a.atom_q[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < nqb) {
+          const double dx = ax - xq[j][0], dy = ay - xq[j][1], dz = az - xq[j][2];
+          const double r = sqrt(dx * dx + dy * dy + dz * dz);  // the reference squares the distance again
+          acc[j] += constant_value * exp(-(r * r) * inv) * qk;
+        }
+      }
+    };
+    if (a.use_lists) {
+      for (int z = b0[2]; z <= b1[2]; ++z)
+        for (int y = b0[1]; y <= b1[1]; ++y)
+          for (int x = b0[0]; x <= b1[0]; ++x) {
+            const int64_t b = (int64_t)x + bn[0] * ((int64_t)y + (int64_t)bn[1] * z);
+            const int ks = a.bin_ptr[b], ke = a.bin_ptr[b + 1];
+            for (int k = ks + lane; k < ke; k += 64) add_atom(a.bin_items[k]);
+          }
+    } else {
+      for (int k = lane; k < a.n_atoms; k += 64) add_atom(k);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double s = wave_sum(acc[j]);
+      if (lane == 0 && j < nqb) a.dens[(size_t)cell * a.nq + qb + j] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- HBM calibration (measurement only)
 // Pure streaming read (16 B / lane, grid-stride) and copy: the ceiling the SpMV is compared with
 // on the device it actually runs on (bench.py reports it next to the 8 TB/s spec figure).

@@ -202,7 +202,7 @@ void ParameterReader::declare_parameters() {
             {"Polynomial degree", "1"}, {"Preconditioner", "GMG"}, {"Lammps input file", "atom_8.data"},
             // additions of this build (the reference selects the smoother by editing :969-970)
             {"Smoother", "SSOR"}, {"Smoother damping", "0.5"}, {"Smoother steps", "2"}, {"Chebyshev degree", "2"},
-            {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}};
+            {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}, {"Charge densities on device", "true"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -263,6 +263,7 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.chebyshev_degree = (int)prm.get_integer("Chebyshev degree");
   p.device_resident_outer_cg = prm.get_bool("Device resident outer CG");
   p.ssor_blocks = (int)prm.get_integer("SSOR blocks");
+  p.densities_on_device = prm.get_bool("Charge densities on device");
   return p;
 }
 
@@ -662,6 +663,31 @@ void LaplaceProblem<dim>::compute_charge_densities() {
   const Quadrature<dim> quad((int)(par.degree + par.quadrature_degree_rhs));
   const size_t nq = quad.p.size();
   density_values_for_each_cell.assign(active_cells.size(), {});
+  if (densities_on_device && dim == 3) {
+    // the same sums on the MI355X (gmg_charge_density), cell geometry in, rho out
+    if (ensure_context() != GMG_OK) throw std::runtime_error("charge densities on the device: " + last_error);
+    const size_t nc = active_cells.size();
+    std::vector<double> lo(3 * nc), hh(nc), rlo(3 * nc), qp(3 * nq), dens(nc * nq);
+    for (size_t ci = 0; ci < nc; ++ci) {
+      const ActiveCell &ac = active_cells[ci];
+      const Cell &cell = triangulation.levels[(size_t)ac.level][(size_t)ac.index];
+      double x0[3];
+      triangulation.cell_origin(ac.level, cell, x0);
+      hh[ci] = triangulation.cell_size(ac.level);
+      for (int d = 0; d < 3; ++d) {
+        lo[3 * ci + (size_t)d] = x0[d];
+        rlo[3 * ci + (size_t)d] = triangulation.origin + triangulation.h0 * (cell.c[d] >> ac.level);
+      }
+    }
+    for (size_t q = 0; q < nq; ++q)
+      for (int d = 0; d < 3; ++d) qp[3 * q + (size_t)d] = quad.p[q][(size_t)d];
+    const int rc = gmg_charge_density(gmg, (int64_t)nc, lo.data(), hh.data(), rlo.data(), triangulation.h0, (int64_t)number_of_atoms,
+                                      atom_positions.data(), charges.data(), par.r_c, par.nonzero_density_radius_parameter * par.r_c,
+                                      par.flag_rhs_assembly ? 1 : 0, (int)nq, qp.data(), dens.data());
+    if (rc != GMG_OK) throw std::runtime_error(std::string("gmg_charge_density: ") + gmg_last_error(gmg));
+    for (size_t ci = 0; ci < nc; ++ci) density_values_for_each_cell[ci].assign(dens.begin() + (std::ptrdiff_t)(ci * nq), dens.begin() + (std::ptrdiff_t)((ci + 1) * nq));
+    return;
+  }
   const double constant_value = 4.0 * M_PI / (std::pow(par.r_c, 3) * std::pow(M_PI, 1.5));
   const double r_c_squared_inverse = 1.0 / (par.r_c * par.r_c);
 #pragma omp parallel
@@ -956,20 +982,30 @@ void LaplaceProblem<dim>::build_transfer() {
   } while (0)
 
 template <int dim>
+int LaplaceProblem<dim>::ensure_context() {
+  if (gmg) return GMG_OK;
+  const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
+  const int rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, 1);
+  if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
+  if (distributed) GMGC(gmg_comm_init(gmg, rank, n_ranks, comm_id.data()));  // once: the id is single-use
+  return GMG_OK;
+}
+
+template <int dim>
 int LaplaceProblem<dim>::upload() {
   const int L = triangulation.n_levels();
-  int rc = GMG_OK;
-  if (gmg) {  // next adaptive cycle: same context (stream, RCCL communicator), new operators
+  const bool had_context = gmg != nullptr && operators_uploaded;
+  int rc = ensure_context();
+  if (rc != GMG_OK) return rc;
+  if (had_context) {  // next adaptive cycle: same context (stream, RCCL communicator), new operators
     for (double *p : {d_solution, d_rhs, d_full})
       if (p) gmg_vec_free(gmg, p);
     d_solution = d_rhs = d_full = nullptr;
     GMGC(gmg_reset(gmg, L));
   } else {
-    const char *dev_env = std::getenv("STEP50_DEVICE");  // one process per GPU: LOCAL_RANK
-    rc = gmg_create(&gmg, dev_env ? std::atoi(dev_env) : 0, L);
-    if (rc != GMG_OK) { last_error = "gmg_create failed: no usable MI355X / HIP runtime"; gmg = nullptr; return rc; }
-    if (distributed) GMGC(gmg_comm_init(gmg, rank, n_ranks, comm_id.data()));  // once: the id is single-use
+    GMGC(gmg_reset(gmg, L));  // the context may have been created early (charge densities) with 1 level
   }
+  operators_uploaded = true;
   GMGC(gmg_set_tuning(gmg, 0, par.ssor_blocks << 8));  // before the level matrices: sizes the SGS schedule
   const CSRMatrix &S = system_matrix;
   if (distributed) {
@@ -1226,6 +1262,7 @@ void LaplaceProblem<dim>::postprocess_electrostatic_energy() {
 template <int dim>
 int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
   pcout("Cycle " + std::to_string(cycle) + ":");
+  densities_on_device = on_device && par.densities_on_device;
   if (cycle == 0) make_initial_grid();
   else refine_grid(cycle);
   reports.emplace_back();

@@ -60,6 +60,7 @@ struct Parameters {
   std::string smoother = "SSOR";  // Jacobi | SSOR | Chebyshev
   double smoother_omega = 0.5;
   int smoother_steps = 2, chebyshev_degree = 2;
+  bool densities_on_device = true;  // compute_charge_densities() through gmg_charge_density when a device is in use
   int ssor_blocks = 1;  // 1: exact sequential SGS (mpirun=1); B: rank-local SGS on B blocks (mpirun=B)
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   static Parameters from(const ParameterReader &prm);
@@ -98,6 +99,7 @@ class LaplaceProblem {
   void assemble_system();                                                // :735-833
   void assemble_multigrid();                                             // :835-933
   void build_transfer();                                                 // mg_transfer.build_matrices, :957-958
+  int ensure_context();                                                  // gmg_create (+ communicator) on first use
   int upload();                                                          // hand the operators over the C-ABI
   int solve();                                                           // :938-1017
   void estimate_error_and_mark_cells();                                  // :1020-1090
@@ -123,6 +125,7 @@ class LaplaceProblem {
   std::string log;  // everything pcout would have printed
   bool echo = false;
   gmg_context *gmg = nullptr;
+  bool operators_uploaded = false, densities_on_device = false;
   std::string last_error;
   // one process per GPU (the reference: one MPI rank per subdomain, src/main.cc:8); the host
   // setup is replicated, the operators are cut by partition.h at upload()

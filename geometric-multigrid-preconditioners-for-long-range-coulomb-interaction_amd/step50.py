@@ -68,6 +68,7 @@ def prm_text(**kw) -> str:
         "steps": ("Solver input data", "Smoother steps"), "cheb_degree": ("Solver input data", "Chebyshev degree"),
         "device_cg": ("Solver input data", "Device resident outer CG"),
         "ssor_blocks": ("Solver input data", "SSOR blocks"),
+        "densities_on_device": ("Misc", "Charge densities on device"),
     }
     sections = {}
     for k, v in kw.items():

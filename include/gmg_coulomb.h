@@ -128,6 +128,17 @@ int gmg_restrict_and_add(gmg_context *ctx, int level, double *dst_coarse, const 
 int gmg_cg_solve(gmg_context *ctx, double *x, const double *b, double rel_tol, int max_it, int precond,
                  int *iterations, double *starting_value, double *convergence_value);
 
+/* ---- next row N1: Gaussian charge density at the quadrature points -------- */
+/* compute_charge_densities() (src/step-50.cc:509-575) with the atom lists of
+ * rhs_assembly_optimization() (:260-306) evaluated on the fly: for every cell, rho at its nq
+ * quadrature points, summed over the atoms closer than `cutoff` to any vertex of the cell's
+ * ROOT cell (use_lists != 0; children inherit the parent's list, :441-450) or over all atoms.
+ * Host arrays in, host array out (dens[n_cells * nq], incl. the factor 4 pi of :522).       */
+int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo, const double *cell_h,
+                       const double *root_lo, double root_h, int64_t n_atoms, const double *atom_xyz,
+                       const double *atom_q, double r_c, double cutoff, int use_lists, int nq,
+                       const double *quadrature_points, double *dens);
+
 /* ---- distributed (one process per GPU, RCCL over xGMI) ------------------------------ */
 #define GMG_UNIQUE_ID_BYTES 128
 int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broadcast by the host */

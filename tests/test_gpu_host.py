@@ -83,3 +83,35 @@ def test_distributed_layout_on_one_rank(golden):
     assert a["cg_iterations"] == b["cg_iterations"] and a["coarse_iterations"] == b["coarse_iterations"]
     xa, xb = p2.vector("solution"), ref.vector("solution")
     assert np.abs(xa - xb).max() <= 1e-9 * np.abs(xb).max()
+
+
+def test_charge_density_on_device_matches_host(golden, golden_dir):
+    """gmg_charge_density (src/step-50.cc:509-575 + the cutoff lists of :260-306)
+    against the host evaluation of the same sums, and against the rhs norms the reference
+    printed (tests/gaussian-charges.mpirun=1.output:10-12; QGauss(5): 125 points per cell)."""
+    g = golden["tests/gaussian-charges.mpirun=1"]["runs"][0]["cycles"][0]
+    rhs = {}
+    for dev in (True, False):
+        for opt in (True, False):
+            p = _problem(left=0, right=1, mesh_size=0.25, vacuum=4 if not opt else 10, problem="GaussianCharges", dim=3, bc="Exact",
+                         cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=opt, quad_rhs=4, global_refinement=0, smoother="Jacobi",
+                         densities_on_device=dev)
+            p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
+            r = p.run_cycle(0)
+            rhs[(dev, opt)] = p.vector("rhs")
+            if opt:
+                for k in ("rhs_l1", "rhs_l2", "rhs_linf"):
+                    assert rel_close(r[k], g[k], 11), (dev, k)
+    for opt in (True, False):
+        a, b = rhs[(True, opt)], rhs[(False, opt)]
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+    # 216 atoms, lists on: many atoms per cell, bins with several atoms
+    out = []
+    for dev in (True, False):
+        p = _problem(left=0, right=3, mesh_size=0.25, vacuum=2, problem="GaussianCharges", dim=3, bc="Inhomogeneous", cycles=1,
+                     r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi",
+                     densities_on_device=dev)
+        p.set_nacl_atoms(3)
+        p.run_cycle(0)
+        out.append(p.vector("rhs"))
+    assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
