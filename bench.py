@@ -87,7 +87,7 @@ def main():
         torch.cuda.synchronize()
 
     os.environ["STEP50_DEVICE"] = str(local_rank)
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, world))))
+    S.set_threads(max(1, (os.cpu_count() or 8) // max(1, world)))  # replicated host setup: share the cores
     p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
                              quad_rhs=1, global_refinement=0, smoother=args.smoother))

@@ -74,7 +74,7 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
       }
     }
     HIPC(hipMemcpyAsync(ctx->st_host, ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(stream_wait(ctx->stream));
     if (ctx->st_host->done) break;
     if (launched > maxit + 1) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
     chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 4;

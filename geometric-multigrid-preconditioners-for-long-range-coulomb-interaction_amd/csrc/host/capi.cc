@@ -8,6 +8,9 @@
 
 #include "laplace_problem.h"
 #include "partition.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace step50;
 
@@ -187,6 +190,15 @@ int step50_constrained_mask(step50_problem *h, int8_t *out) {
   return 0;
 }
 void *step50_gmg_context(step50_problem *h) { return DISPATCH(h, gmg); }
+
+// host threads of the replicated setup (one process per GPU: cores / world size)
+void step50_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
 
 // one process per GPU: rank, world size and the 128-byte id of gmg_comm_unique_id (rank 0)
 int step50_set_communicator(step50_problem *h, int rank, int n_ranks, const void *id128) {

@@ -50,6 +50,10 @@ def load(build_if_missing: bool = False):
     return _lib
 
 
+def set_threads(n: int):
+    load().step50_set_threads(C.c_int(n))
+
+
 def prm_text(**kw) -> str:
     """A .prm file body with the reference's keys (src/step-50.cc:13-95)."""
     keymap = {
