@@ -52,14 +52,14 @@ def build_host(force=False, verbose=False):
     if force or _newer(LIB_HOST, srcs):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-fopenmp",
                "-I" + os.path.join(HERE, "..", "include"), "-o", LIB_HOST] + lib_srcs + \
-              ["-L" + CSRC, "-lgmgcoulomb", "-Wl,-rpath," + CSRC, "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+              ["-L" + CSRC, "-lgmgcoulomb", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     main_cc = os.path.join(HOST, "main.cc")
     if os.path.exists(main_cc) and (force or _newer(EXE_HOST, srcs)):
         cmd = ["g++", "-O2", "-std=c++17", "-fopenmp", "-I" + os.path.join(HERE, "..", "include"), "-o", EXE_HOST, main_cc,
-               "-L" + HOST, "-lstep50host", "-L" + CSRC, "-lgmgcoulomb", "-Wl,-rpath," + HOST, "-Wl,-rpath," + CSRC,
+               "-L" + HOST, "-lstep50host", "-L" + CSRC, "-lgmgcoulomb", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/..",
                "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd))
