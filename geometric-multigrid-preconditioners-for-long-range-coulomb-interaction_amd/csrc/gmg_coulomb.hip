@@ -89,7 +89,9 @@ struct gmg_context {
   int64_t cg_n = 0;
   double *cg_g = nullptr, *cg_d0 = nullptr, *cg_d1 = nullptr, *cg_h = nullptr;
   CGState *st = nullptr;       // device
-  CGState *st_host = nullptr;  // pinned
+  CGState *st_host = nullptr;  // pinned, 2 slots (the chunk being checked / the speculative one)
+  CGState st_final{};
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   double *part_a = nullptr, *part_b = nullptr;  // reduction partials (4 * kMaxPartials each)
   double *scal_dev = nullptr;                   // 8 doubles
   double *scal_host = nullptr;                  // pinned, 8 doubles
@@ -520,7 +522,45 @@ void collect_profile_samples(gmg_context *ctx) {
   }
 }
 
-constexpr int64_t kUnfusedMinRowsDecl = 400000;  // == kUnfusedMinRows in gmg_dist.hpp
+constexpr int64_t kUnfusedMinRowsDecl = 400000;
+
+// Enqueues coarse-CG iterations in chunks and watches the 64-byte device state.  The first
+// chunk is sized from the previous solve (zero-start solves of one hierarchy need nearly the
+// same number of iterations); while the host waits for a chunk's state, the NEXT chunk is
+// already queued, so the GPU never idles on the host round trip -- iterations enqueued after
+// convergence return at once (the `done` flag, ~1 us each).
+template <class EnqueueOne>
+int run_cg_chunks(gmg_context *ctx, EnqueueOne enqueue_one) {
+  const int maxit = ctx->coarse_maxit;
+  const int first = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (ctx->last_coarse_iters > 8 ? ctx->last_coarse_iters - 2 : 16);
+  const int later = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 6;
+  int launched = 0;
+  auto launch_chunk = [&](int n, int slot) -> int {
+    for (int q = 0; q < n; ++q) {
+      const int rc = enqueue_one(launched++);
+      if (rc != GMG_OK) return rc;
+    }
+    HIPC(hipMemcpyAsync(&ctx->st_host[slot], ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipEventRecord(ctx->ev_chunk[slot], ctx->stream));
+    return GMG_OK;
+  };
+  int slot = 0;
+  CHK(launch_chunk(std::min(first, maxit + 1), slot));
+  const bool speculate = !ctx->dist;  // no-op iterations still exchange halos / all-reduce: not worth it across ranks
+  for (;;) {
+    if (speculate) CHK(launch_chunk(later, slot ^ 1));
+    for (;;) {
+      const hipError_t e = hipEventQuery(ctx->ev_chunk[slot]);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
+    }
+    if (ctx->st_host[slot].done) { ctx->st_final = ctx->st_host[slot]; break; }
+    if (launched > maxit + 2 * later + 2) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
+    if (!speculate) CHK(launch_chunk(later, slot ^ 1));
+    slot ^= 1;
+  }
+  return GMG_OK;
+}  // == kUnfusedMinRows in gmg_dist.hpp
 
 // ---- coarse solver (A9): device-resident classic CG on level 0 -----------------------------
 
@@ -545,50 +585,36 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   CGInitArgs ia{b, x, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, n, ctx->st, ctx->part_b};
   hipLaunchKernelGGL(cg_init_kernel, dim3(g_init), dim3(kThreads), 0, ctx->stream, ia);
   int n_part_gg = g_init;
-  int launched = 0;
   const int maxit = ctx->coarse_maxit;
-  // chunking: enqueue `chunk` iterations, then look at the device state.  The first chunk is
-  // sized from the previous solve's count (zero-start solves of one hierarchy need nearly the
-  // same number of iterations), later chunks are short.
-  int chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (ctx->last_coarse_iters > 8 ? ctx->last_coarse_iters - 2 : 16);
   ctx->ev_used = 0; ctx->ev2_used = 0;
-  for (;;) {
-    // "maxit + 1" SpMV-kernel launches are needed to *observe* failure at it == maxit
-    int todo = std::min(chunk, maxit + 1 - launched);
-    if (todo <= 0) todo = 1;
-    for (int q = 0; q < todo; ++q, ++launched) {
-      const bool odd = launched & 1;
-      SpmvArgs a = base_args(A, odd ? ctx->cg_d1 : ctx->cg_d0, ctx->cg_h);
-      a.g = ctx->cg_g;
-      a.dnew = odd ? ctx->cg_d0 : ctx->cg_d1;
-      a.st = ctx->st;
-      a.part_in = ctx->part_b; a.n_part_in = n_part_gg;
-      a.part_out = ctx->part_a;
-      a.tol = ctx->coarse_tol; a.maxit = maxit;
-      const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
-      if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
-      const int n_part_dh = launch_op<kStore, 1>(ctx, A, a);
-      if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
-      CGUpdateArgs ua{x, ctx->cg_g, a.dnew, ctx->cg_h, n, ctx->st, ctx->part_a, n_part_dh, ctx->part_b};
-      const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
-      if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
-      hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
-      if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
-      n_part_gg = g_upd;
-    }
-    HIPC(hipMemcpyAsync(ctx->st_host, ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(stream_wait(ctx->stream));
-    if (ctx->st_host->done) break;
-    if (launched > maxit + 1) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
-    chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 4;
-  }
+  CHK(run_cg_chunks(ctx, [&](int launched) -> int {
+    const bool odd = launched & 1;
+    SpmvArgs a = base_args(A, odd ? ctx->cg_d1 : ctx->cg_d0, ctx->cg_h);
+    a.g = ctx->cg_g;
+    a.dnew = odd ? ctx->cg_d0 : ctx->cg_d1;
+    a.st = ctx->st;
+    a.part_in = ctx->part_b; a.n_part_in = n_part_gg;
+    a.part_out = ctx->part_a;
+    a.tol = ctx->coarse_tol; a.maxit = maxit;
+    const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
+    if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
+    const int n_part_dh = launch_op<kStore, 1>(ctx, A, a);
+    if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
+    CGUpdateArgs ua{x, ctx->cg_g, a.dnew, ctx->cg_h, n, ctx->st, ctx->part_a, n_part_dh, ctx->part_b};
+    const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
+    if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
+    if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+    n_part_gg = g_upd;
+    return GMG_OK;
+  }));
   collect_profile_samples(ctx);
-  ctx->last_coarse_iters = ctx->st_host->iters;
+  ctx->last_coarse_iters = ctx->st_final.iters;
   ctx->stats.coarse_solves++;
-  ctx->stats.coarse_iterations += ctx->st_host->iters;
-  if (iters_out) *iters_out = ctx->st_host->iters;
-  if (res_out) *res_out = ctx->st_host->res;
-  if (ctx->st_host->status != 0) return fail(ctx, GMG_ERR_COARSE_NOCONV, "coarse CG did not converge within max_it");
+  ctx->stats.coarse_iterations += ctx->st_final.iters;
+  if (iters_out) *iters_out = ctx->st_final.iters;
+  if (res_out) *res_out = ctx->st_final.res;
+  if (ctx->st_final.status != 0) return fail(ctx, GMG_ERR_COARSE_NOCONV, "coarse CG did not converge within max_it");
   return GMG_OK;
 }
 
@@ -810,7 +836,9 @@ int gmg_create(gmg_context **out, int device_id, int n_levels) {
   auto bail = [&](int code) { gmg_destroy(ctx); return code; };
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipMalloc(&ctx->st, sizeof(CGState)) != hipSuccess) return bail(GMG_ERR_HIP);
-  if (hipHostMalloc((void **)&ctx->st_host, sizeof(CGState), hipHostMallocDefault) != hipSuccess) return bail(GMG_ERR_HIP);
+  if (hipHostMalloc((void **)&ctx->st_host, 2 * sizeof(CGState), hipHostMallocDefault) != hipSuccess) return bail(GMG_ERR_HIP);
+  for (auto &e : ctx->ev_chunk)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipMalloc(&ctx->part_a, sizeof(double) * 4 * kMaxPartials) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipMalloc(&ctx->part_b, sizeof(double) * 4 * kMaxPartials) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipMalloc(&ctx->scal_dev, sizeof(double) * 8) != hipSuccess) return bail(GMG_ERR_HIP);
@@ -830,6 +858,8 @@ int gmg_destroy(gmg_context *ctx) {
     if (p) (void)hipFree(p);
   if (ctx->st) (void)hipFree(ctx->st);
   if (ctx->st_host) (void)hipHostFree(ctx->st_host);
+  for (auto &e : ctx->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->scal_host) (void)hipHostFree(ctx->scal_host);
   for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d})
     for (hipEvent_t e : *v) (void)hipEventDestroy(e);

@@ -37,55 +37,45 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
   }
 
   const int maxit = ctx->coarse_maxit;
-  int launched = 0;
-  int chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (ctx->last_coarse_iters > 8 ? ctx->last_coarse_iters - 2 : 16);
   ctx->ev_used = 0; ctx->ev2_used = 0;
-  for (;;) {
-    int todo = std::min(chunk, maxit + 1 - launched);
-    if (todo <= 0) todo = 1;
-    for (int q = 0; q < todo; ++q, ++launched) {
-      CGDirArgs da{d, ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
-      hipLaunchKernelGGL(cg_direction_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, da);
-      if (comm && halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
-      SpmvArgs a = base_args(A, d, ctx->cg_h);
-      a.st = ctx->st;
-      a.part_out = ctx->part_a;
-      const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
-      if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
-      const int n_part_dh = launch_op<kStore, 2>(ctx, A, a);
-      if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
-      const double *dh_src = ctx->part_a;
-      int dh_n = n_part_dh;
-      if (comm) {
-        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, n_part_dh, 1, 0u, s_dh);
-        if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
-        dh_src = s_dh; dh_n = 1;
-      }
-      CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
-      const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
-      if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
-      hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
-      if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
-      if (comm) {
-        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);
-        if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
-      } else {
-        gg_src = ctx->part_b; gg_n = g_upd;
-      }
+  CHK(run_cg_chunks(ctx, [&](int launched) -> int {
+    CGDirArgs da{d, ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, da);
+    if (comm && halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
+    SpmvArgs a = base_args(A, d, ctx->cg_h);
+    a.st = ctx->st;
+    a.part_out = ctx->part_a;
+    const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
+    if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
+    const int n_part_dh = launch_op<kStore, 2>(ctx, A, a);
+    if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
+    const double *dh_src = ctx->part_a;
+    int dh_n = n_part_dh;
+    if (comm) {
+      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_a, n_part_dh, 1, 0u, s_dh);
+      if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+      dh_src = s_dh; dh_n = 1;
     }
-    HIPC(hipMemcpyAsync(ctx->st_host, ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(stream_wait(ctx->stream));
-    if (ctx->st_host->done) break;
-    if (launched > maxit + 1) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
-    chunk = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 4;
-  }
+    CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
+    const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
+    if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
+    if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+    if (comm) {
+      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);
+      if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
+    } else {
+      gg_src = ctx->part_b; gg_n = g_upd;
+    }
+    return GMG_OK;
+  }));
   collect_profile_samples(ctx);
-  ctx->last_coarse_iters = ctx->st_host->iters;
+  ctx->last_coarse_iters = ctx->st_final.iters;
   ctx->stats.coarse_solves++;
-  ctx->stats.coarse_iterations += ctx->st_host->iters;
-  if (iters_out) *iters_out = ctx->st_host->iters;
-  if (res_out) *res_out = ctx->st_host->res;
-  if (ctx->st_host->status != 0) return fail(ctx, GMG_ERR_COARSE_NOCONV, "coarse CG did not converge within max_it");
+  ctx->stats.coarse_iterations += ctx->st_final.iters;
+  if (iters_out) *iters_out = ctx->st_final.iters;
+  if (res_out) *res_out = ctx->st_final.res;
+  if (ctx->st_final.status != 0) return fail(ctx, GMG_ERR_COARSE_NOCONV, "coarse CG did not converge within max_it");
   return GMG_OK;
 }
 
