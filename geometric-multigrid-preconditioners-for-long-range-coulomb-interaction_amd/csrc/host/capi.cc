@@ -123,7 +123,7 @@ struct step50_report {
   double rhs_l1, rhs_l2, rhs_linf, matrix_l1, matrix_linf, matrix_frobenius;
   double starting_value, convergence_value, sol_l1, sol_l2, sol_linf, refine_threshold;
   double energy_analytical, energy_short, energy_fe_long, energy_self, energy_total, energy_abs_error;
-  double solve_seconds;
+  double solve_seconds, energy_norm_error;
 };
 int step50_get_report(step50_problem *h, int i, step50_report *out) {
   const auto &reps = DISPATCH(h, reports);
@@ -142,6 +142,7 @@ int step50_get_report(step50_problem *h, int i, step50_report *out) {
   out->energy_analytical = r.energy_analytical; out->energy_short = r.energy_short; out->energy_fe_long = r.energy_fe_long;
   out->energy_self = r.energy_self; out->energy_total = r.energy_total; out->energy_abs_error = r.energy_abs_error;
   out->solve_seconds = r.solve_seconds;
+  out->energy_norm_error = r.energy_norm_error;
   return 0;
 }
 

@@ -1257,6 +1257,46 @@ void LaplaceProblem<dim>::postprocess_electrostatic_energy() {
   pcout("Relative Error in total electrostatic energy :\t" + fmt("%.10e", std::fabs((std::fabs(analytical) - std::fabs(rep.energy_total)) / analytical)));
 }
 
+template <int dim>
+void LaplaceProblem<dim>::postprocess_error_in_energy_norm() {
+  // :1423-1461 -- || grad phi_h - grad phi_exact ||_L2 with QGauss(degree+1) per cell and the
+  // analytical gradient of include/step_50.h:355-369 (GaussianCharges only; the reference
+  // dereferences a null exact_solution for Step16).
+  if (par.Problemtype != "GaussianCharges") return;
+  constexpr int nv = 1 << dim;
+  const Quadrature<dim> quad((int)par.degree + 1);
+  const double inv_constant = 1.0 / (std::sqrt(M_PI) * par.r_c);
+  double Error = 0.0;
+#pragma omp parallel for reduction(+ : Error) schedule(dynamic, 512)
+  for (int64_t ci = 0; ci < (int64_t)active_cells.size(); ++ci) {
+    const ActiveCell &ac = active_cells[(size_t)ci];
+    const Cell &cell = triangulation.levels[(size_t)ac.level][(size_t)ac.index];
+    const double h = triangulation.cell_size(ac.level);
+    double x0[3];
+    triangulation.cell_origin(ac.level, cell, x0);
+    int32_t dofs[nv];
+    cell_dofs(ac, dofs);
+    for (size_t q = 0; q < quad.p.size(); ++q) {
+      double xq[3] = {0, 0, 0}, gh[3] = {0, 0, 0}, ga[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) xq[d] = x0[d] + h * quad.p[q][(size_t)d];
+      for (int a = 0; a < nv; ++a)
+        for (int d = 0; d < dim; ++d) gh[d] += solution[(size_t)dofs[a]] * quad.grad[q][(size_t)a][(size_t)d] / h;
+      for (unsigned i = 0; i < number_of_atoms; ++i) {
+        double r2 = 0, dir[3] = {0, 0, 0};
+        for (int d = 0; d < dim; ++d) { dir[d] = xq[d] - atom_positions[3 * i + (size_t)d]; r2 += dir[d] * dir[d]; }
+        const double r = std::sqrt(r2);
+        const double f = charges[i] * (((2.0 * r * std::exp(-std::pow(r / par.r_c, 2)) * inv_constant) - std::erf(r / par.r_c)) / std::pow(r, 2));
+        for (int d = 0; d < dim; ++d) ga[d] += f * dir[d] / r;
+      }
+      double n2 = 0;
+      for (int d = 0; d < dim; ++d) n2 += (gh[d] - ga[d]) * (gh[d] - ga[d]);
+      Error += n2 * quad.w[q] * std::pow(h, dim);
+    }
+  }
+  reports.back().energy_norm_error = std::sqrt(Error);
+  pcout("Error in FE solution in energy norm:  " + fmt("%.10e", std::sqrt(Error)));
+}
+
 // ======================================================================== adaptive loop
 
 template <int dim>
@@ -1296,7 +1336,10 @@ int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
 template <int dim>
 void LaplaceProblem<dim>::finish_cycle() {
   estimate_error_and_mark_cells();                                               // :1552
-  if (lammpsinput && number_of_atoms < 300) postprocess_electrostatic_energy();  // :1554-1555
+  if (lammpsinput && number_of_atoms < 300) {
+    postprocess_electrostatic_energy();     // :1554-1555
+    postprocess_error_in_energy_norm();     // :1556 (O(cells x atoms): kept under the same small-system gate)
+  }
 }
 
 // Test hook: a solution computed elsewhere (the CPU oracle in tests/) takes the place of solve();
@@ -1309,6 +1352,7 @@ void LaplaceProblem<dim>::set_solution(const std::vector<double> &x) {
 
 template <int dim>
 void LaplaceProblem<dim>::run() {
+  pcout("Running with the MI355X C-ABI backend on " + std::to_string(n_ranks) + " rank(s)...");  // :1466-1474
   pcout("Dimension:\t" + std::to_string(dim));
   if (!lammpsinput && number_of_atoms == 0) read_lammps_input_file(par.LammpsInputFile);
   for (unsigned int cycle = 0; cycle < par.number_of_adaptive_refinement_cycles; ++cycle) {

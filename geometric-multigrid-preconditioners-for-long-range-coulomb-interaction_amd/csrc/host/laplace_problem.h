@@ -77,6 +77,7 @@ struct CycleReport {  // the values the reference prints per cycle (src/step-50.
   double refine_threshold = 0;
   bool has_energy = false;
   double energy_analytical = 0, energy_short = 0, energy_fe_long = 0, energy_self = 0, energy_total = 0, energy_abs_error = 0;
+  double energy_norm_error = 0;
   double solve_seconds = 0;  // first residual to convergence, excluding upload / build_matrices
   int status = 0;
 };
@@ -105,6 +106,7 @@ class LaplaceProblem {
   void estimate_error_and_mark_cells();                                  // :1020-1090
   void refine_grid(unsigned int cycle);                                  // :1095-1121
   void postprocess_electrostatic_energy();                               // :1310-1420
+  void postprocess_error_in_energy_norm();                               // :1423-1461
   int run_cycle(unsigned int cycle, bool on_device = true);              // one iteration of the loop in run()
   void finish_cycle();                                   // estimator + energy, the tail of the loop body
   void set_solution(const std::vector<double> &x);       // test hook, see laplace_problem.cc

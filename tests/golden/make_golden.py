@@ -36,7 +36,9 @@ LOGS = {
     "cluster/without_opti": "Cluster runs output and postprocessing/without_opti.o875054",
 }
 
-ATOM_FILES = ["tests/atom_n1_2.data", "tests/atom_2.data", "atom/atom_n1_8.data", "atom/atom_n3_216.data"]
+ATOM_FILES = ["tests/atom_n1_2.data", "tests/atom_2.data", "atom/atom_n1_8.data", "atom/atom_n3_216.data",
+              # expected output of the reference's current regression test, compared line by line with ./step50_mi355x
+              "tests/gaussian-charges.mpirun=1.output"]
 
 NUM = r"([-+0-9.eE]+|nan|inf)"
 FIELDS = [

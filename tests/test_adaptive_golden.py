@@ -37,7 +37,7 @@ def check_cycle(r, g, digits=11):
     assert r["cg_iterations"] == g["cg_iterations"]
     assert abs(r["starting_value"] - g["starting_value"]) < 0.6e-10
     assert abs(r["convergence_value"] - g["convergence_value"]) <= 2e-5 * g["convergence_value"]
-    for k in ("sol_l1", "sol_l2", "sol_linf", "refine_threshold"):
+    for k in ("sol_l1", "sol_l2", "sol_linf", "refine_threshold", "energy_norm_error"):
         assert rel_close(r[k], g[k], digits), (k, r[k], g[k])
     for k, gk in (("energy_analytical", "energy_analytical"), ("energy_short", "energy_short"),
                   ("energy_fe_long", "energy_fe_long"), ("energy_self", "energy_self"), ("energy_total", "energy_total_split")):

@@ -115,3 +115,45 @@ def test_charge_density_on_device_matches_host(golden, golden_dir):
         p.run_cycle(0)
         out.append(p.vector("rhs"))
     assert np.abs(out[0] - out[1]).max() <= 1e-13 * np.abs(out[1]).max()
+
+
+def test_cli_output_diffs_against_reference_output_file(golden_dir, tmp_path):
+    """./step50_mi355x file.prm (the counterpart of the reference's ./main, src/main.cc) on the
+    parameters of tests/gaussian-charges.cc: every line the reference's expected output
+    (tests/gaussian-charges.mpirun=1.output) shares with ours is compared number by number,
+    the way deal.II's numdiff-based test harness does."""
+    import re
+    import subprocess
+
+    exe = pkg().build.EXE_HOST
+    prm = tmp_path / "gaussian-charges.prm"
+    prm.write_text(pkg().step50.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
+                                         cycles=6, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0,
+                                         smoother="SSOR", lammps=os.path.join(golden_dir, "atom_n1_2.data")))
+    out = subprocess.run([exe, str(prm)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    num = re.compile(r"(?<![A-Za-z_])[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?")
+
+    def keyed(text):
+        d, cycle = {}, None
+        for line in text.splitlines():
+            line = line.strip()
+            m = re.match(r"Cycle (\d+):", line)
+            if m:
+                cycle = int(m.group(1))
+                continue
+            label = num.sub("#", line)
+            if cycle is not None and num.search(line):
+                d.setdefault((cycle, label), [float(x) for x in num.findall(line)])
+        return d
+
+    ours = keyed(out.stdout)
+    ref = keyed(open(os.path.join(golden_dir, "gaussian-charges.mpirun=1.output")).read())
+    shared = [k for k in ref if k in ours]
+    assert len(shared) >= 6 * 20  # >= 20 labelled lines in each of the 6 cycles
+    for k in shared:
+        for a, b in zip(ours[k], ref[k]):
+            tol = 2e-5 if "Convergence value" in k[1] else 2e-10
+            assert abs(a - b) <= tol * max(abs(b), 1e-300) or abs(a - b) < 1e-12, (k, a, b)
+    missing = sorted({k[1] for k in ref if k not in ours})
+    assert missing == [], missing
