@@ -49,6 +49,14 @@ struct SgsPlan {
   int32_t *stage_ptr = nullptr, *stage_rows = nullptr, *block_row = nullptr, *block_stage = nullptr;
   int n_blocks = 0;
   int n_stages_max = 0;
+  // packed / LDS variant (every block <= kSgsLdsRows rows)
+  bool packed = false;
+  int32_t *block_slot = nullptr, *slot_row = nullptr, *block_w = nullptr;
+  uint8_t *step_last = nullptr;
+  int64_t *block_pk = nullptr;
+  double *pk_val = nullptr, *slot_invd = nullptr, *r_slot = nullptr;
+  uint16_t *pk_col = nullptr;
+  int max_block_rows = 0, n_slots = 0, lds_bytes = 0;
 };
 
 struct Level {
@@ -427,6 +435,16 @@ int dot_host(gmg_context *ctx, const double *x, const double *y, int64_t n, doub
 // ---- smoothers (A7) ---------------------------------------------------------------------
 
 int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
+  if (L.sgs.packed) {
+    SgsPackedArgs p{};
+    p.block_row = L.sgs.block_row; p.block_slot = L.sgs.block_slot; p.block_pk = L.sgs.block_pk; p.block_w = L.sgs.block_w;
+    p.slot_row = L.sgs.slot_row; p.slot_invd = L.sgs.slot_invd; p.step_last = L.sgs.step_last;
+    p.pk_val = L.sgs.pk_val; p.pk_col = L.sgs.pk_col; p.omega = ctx->omega; p.r = r; p.r_slot = L.sgs.r_slot; p.y = y;
+    p.n_slots = L.sgs.n_slots;
+    hipLaunchKernelGGL(sgs_gather_rhs_kernel, dim3(grid_for(L.sgs.n_slots)), dim3(kThreads), 0, ctx->stream, p);
+    hipLaunchKernelGGL(sgs_packed_kernel, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
+    return GMG_OK;
+  }
   HIPC(hipMemsetAsync(y, 0, sizeof(double) * (size_t)L.n, ctx->stream));
   SgsArgs a{};
   a.rowptr = L.A.rowptr; a.col = L.A.col; a.val = L.A.val; a.invd = L.invd;
@@ -741,7 +759,7 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
 
 // SGS level schedule on the symmetrised pattern, per block of consecutive rows:
 // stage(i) = 1 + max stage(j) over the coupled j < i of the same block.
-int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col) {
+int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col, const double *val) {
   std::vector<int64_t> trp;
   std::vector<int32_t> tcol;
   std::vector<double> tval, ones((size_t)rp[n], 1.0);
@@ -786,6 +804,89 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
   HIPC(hipMemcpyAsync(L.sgs.block_row, block_row.data(), sizeof(int32_t) * block_row.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(L.sgs.block_stage, block_stage.data(), sizeof(int32_t) * block_stage.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
+  // ---- packed / LDS variant when every block's y slice fits the LDS
+  for (void **p : {(void **)&L.sgs.block_slot, (void **)&L.sgs.slot_row, (void **)&L.sgs.block_w, (void **)&L.sgs.step_last,
+                   (void **)&L.sgs.block_pk, (void **)&L.sgs.pk_val, (void **)&L.sgs.pk_col, (void **)&L.sgs.slot_invd, (void **)&L.sgs.r_slot})
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  L.sgs.packed = false;
+  int max_rows = 0;
+  for (int b = 0; b < n_blocks; ++b) max_rows = std::max(max_rows, block_row[(size_t)b + 1] - block_row[(size_t)b]);
+  const char *no_pk = std::getenv("GMG_DISABLE_SGS_PACKED");
+  if (max_rows > 0 && max_rows <= kSgsLdsRows && !(no_pk && no_pk[0] == '1')) {
+    std::vector<int32_t> block_slot((size_t)n_blocks + 1, 0), slot_row, block_w((size_t)n_blocks, 32);
+    std::vector<uint8_t> step_last;
+    std::vector<int64_t> block_pk((size_t)n_blocks, 0);
+    std::vector<double> slot_invd;
+    int64_t total = 0;
+    int max_lds = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+      const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
+      int w = 1;
+      for (int64_t i = rb; i < re; ++i) {
+        int c = 0;
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) c += (col[k] >= rb && col[k] < re);
+        w = std::max(w, c);
+      }
+      block_w[(size_t)b] = (w + 31) / 32 * 32;
+      // slots: each stage padded to a multiple of 32 rows
+      const int so = block_stage[(size_t)b] + b, ns = block_stage[(size_t)b + 1] - block_stage[(size_t)b];
+      const size_t slot0 = slot_row.size();
+      for (int t = 0; t < ns; ++t) {
+        const int qb = sp[(size_t)(so + t)], qe = sp[(size_t)(so + t + 1)];
+        for (int q = qb; q < qe; q += 32) {
+          for (int u = 0; u < 32; ++u) slot_row.push_back(q + u < qe ? rows[(size_t)(q + u)] : -1);
+          step_last.push_back(q + 32 >= qe ? 1 : 0);
+        }
+      }
+      block_slot[(size_t)b + 1] = (int32_t)slot_row.size();
+      block_pk[(size_t)b] = total;
+      total += (int64_t)(slot_row.size() - slot0) * block_w[(size_t)b];
+      const int n_steps = (int)((slot_row.size() - slot0) / 32);
+      max_lds = std::max(max_lds, (int)(8 * (re - rb) + ((n_steps + 15) / 16) * 16));
+    }
+    if (max_lds <= 160 * 1024 && total < ((int64_t)1 << 31)) {
+      const size_t n_slots = slot_row.size();
+      std::vector<double> pk_val((size_t)std::max<int64_t>(total, 1), 0.0);
+      std::vector<uint16_t> pk_col((size_t)std::max<int64_t>(total, 1), 0);
+      slot_invd.assign(std::max<size_t>(n_slots, 1), 0.0);
+      for (int b = 0; b < n_blocks; ++b) {
+        const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
+        const int w = block_w[(size_t)b];
+        for (int64_t sl = block_slot[(size_t)b]; sl < block_slot[(size_t)b + 1]; ++sl) {
+          const int64_t i = slot_row[(size_t)sl];
+          const int64_t o = block_pk[(size_t)b] + (sl - block_slot[(size_t)b]) * w;
+          if (i < 0) continue;  // padding slot: zero records, never executed (row = -1)
+          int c = 0;
+          double aii = 1.0;
+          for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+            if (col[k] == i) aii = val[k];
+            if (col[k] >= rb && col[k] < re) { pk_val[(size_t)(o + c)] = val[k]; pk_col[(size_t)(o + c)] = (uint16_t)(col[k] - rb); ++c; }
+          }
+          for (; c < w; ++c) { pk_val[(size_t)(o + c)] = 0.0; pk_col[(size_t)(o + c)] = (uint16_t)(i - rb); }
+          slot_invd[(size_t)sl] = 1.0 / aii;
+        }
+      }
+#define SGS_UP(dst, vec, T)                                                                                         \
+  HIPC(hipMalloc(&dst, sizeof(T) * std::max<size_t>((vec).size(), 1)));                                              \
+  if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
+      SGS_UP(L.sgs.block_slot, block_slot, int32_t)
+      SGS_UP(L.sgs.slot_row, slot_row, int32_t)
+      SGS_UP(L.sgs.step_last, step_last, uint8_t)
+      SGS_UP(L.sgs.block_w, block_w, int32_t)
+      SGS_UP(L.sgs.block_pk, block_pk, int64_t)
+      SGS_UP(L.sgs.pk_val, pk_val, double)
+      SGS_UP(L.sgs.pk_col, pk_col, uint16_t)
+      SGS_UP(L.sgs.slot_invd, slot_invd, double)
+#undef SGS_UP
+      HIPC(hipMalloc(&L.sgs.r_slot, sizeof(double) * std::max<size_t>(n_slots, 1)));
+      HIPC(hipStreamSynchronize(ctx->stream));
+      L.sgs.packed = true;
+      L.sgs.max_block_rows = max_rows;
+      L.sgs.n_slots = (int)n_slots;
+      L.sgs.lds_bytes = max_lds;
+      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+  }
   return GMG_OK;
 }
 
@@ -799,7 +900,9 @@ void release_operators(gmg_context *ctx) {
       if (p) (void)hipFree(p);
     if (L.copy_g) (void)hipFree(L.copy_g);
     if (L.copy_l) (void)hipFree(L.copy_l);
-    for (int32_t *p : {L.sgs.stage_ptr, L.sgs.stage_rows, L.sgs.block_row, L.sgs.block_stage})
+    for (void *p : {(void *)L.sgs.stage_ptr, (void *)L.sgs.stage_rows, (void *)L.sgs.block_row, (void *)L.sgs.block_stage,
+                    (void *)L.sgs.block_slot, (void *)L.sgs.slot_row, (void *)L.sgs.block_w, (void *)L.sgs.step_last,
+                    (void *)L.sgs.block_pk, (void *)L.sgs.pk_val, (void *)L.sgs.pk_col, (void *)L.sgs.slot_invd, (void *)L.sgs.r_slot})
       if (p) (void)hipFree(p);
     L = Level();
   }
@@ -916,7 +1019,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
   L.n_vec = n_cols;
   CHK(setup_diag(ctx, n_rows, rowptr, col, val, &L.invd, &L.cheb_lmax));
   for (double **p : {&L.sol, &L.def, &L.t, &L.w1, &L.w2, &L.w3}) CHK(alloc_vec(ctx, p, n_cols));
-  if (level > 0) CHK(setup_sgs(ctx, L, n_rows, rowptr, col));
+  if (level > 0) CHK(setup_sgs(ctx, L, n_rows, rowptr, col, val));
   if (level == 0) {
     if (ctx->dist) {
       const int64_t padded = part_chunk(ctx->l0_global, ctx->comm.n_ranks) * ctx->comm.n_ranks;
