@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <climits>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -40,6 +41,8 @@ struct DevCSR {
   void *sell_vals = nullptr;     // uchar4 codes (VAL8) or double2 pairs
   void *sell_cols = nullptr;     // ushort4 offsets (COL16) or int4 columns
   double *sell_dict = nullptr;   // VAL8: 256 doubles
+  int32_t *sell_spat = nullptr, *sell_pat = nullptr;  // column-pattern ids per slice / pattern table
+  int n_patterns = 0, n_pattern_slices = 0;
   bool val8 = false, col16 = false;
   int n_slices = 0, sell_grid = 0;
   int64_t sell_quads = 0;
@@ -172,6 +175,8 @@ void free_csr(DevCSR &m) {
   if (m.sell_vals) (void)hipFree(m.sell_vals);
   if (m.sell_cols) (void)hipFree(m.sell_cols);
   if (m.sell_dict) (void)hipFree(m.sell_dict);
+  if (m.sell_spat) (void)hipFree(m.sell_spat);
+  if (m.sell_pat) (void)hipFree(m.sell_pat);
   free_halo(m.halo);
   m = DevCSR();
 }
@@ -235,10 +240,38 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
     const char *dbg = std::getenv("GMG_DEBUG_NOGATHER");  // timing experiments only: every column -> own row
     const bool debug_nogather = dbg && dbg[0] == '1';
     std::vector<int32_t> sp((size_t)n_slices + 1, 0);
+    // column patterns: a slice qualifies when all 64 rows exist and the union of (col - row) over
+    // its rows has <= 32 members that are valid columns for every row; rows lacking a member get an
+    // explicit +0.0 there (exact: x is finite), which keeps the CSR summation order
+    const char *no_pat = std::getenv("GMG_DISABLE_PATTERNS");
+    const bool allow_pat = !(no_pat && no_pat[0] == '1') && n_rows == n_cols;
+    std::vector<int32_t> spat((size_t)n_slices, -1);
+    std::vector<std::vector<int32_t>> patterns;
+    std::map<std::vector<int32_t>, int> pattern_id;
     int64_t quads = 0;
     for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
       int64_t w = 0;
       for (int64_t r2 = sidx * 64; r2 < std::min<int64_t>(n_rows, sidx * 64 + 64); ++r2) w = std::max(w, rowptr[r2 + 1] - rowptr[r2]);
+      if (allow_pat && sidx * 64 + 64 <= n_rows) {
+        std::vector<int32_t> delta;
+        for (int64_t r2 = sidx * 64; r2 < sidx * 64 + 64 && delta.size() <= 32; ++r2)
+          for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) {
+            const int32_t d = (int32_t)(col[k] - r2);
+            auto it = std::lower_bound(delta.begin(), delta.end(), d);
+            if (it == delta.end() || *it != d) delta.insert(it, d);
+          }
+        bool ok = !delta.empty() && delta.size() <= 32;
+        if (ok) ok = sidx * 64 + delta.front() >= 0 && sidx * 64 + 63 + delta.back() < n_cols;
+        // columns must be strictly ascending inside each row for the positions to be well defined
+        for (int64_t r2 = sidx * 64; ok && r2 < sidx * 64 + 64; ++r2)
+          for (int64_t k = rowptr[r2] + 1; k < rowptr[r2 + 1]; ++k) ok = ok && col[k] > col[k - 1];
+        if (ok && (int64_t)delta.size() <= ((w + 3) / 4) * 4 + 4) {
+          auto ins = pattern_id.emplace(delta, (int)patterns.size());
+          if (ins.second) patterns.push_back(delta);
+          spat[(size_t)sidx] = ins.first->second;
+          w = (int64_t)delta.size();
+        }
+      }
       quads += (w + 3) / 4;
       sp[(size_t)sidx + 1] = (int32_t)quads;
     }
@@ -275,6 +308,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
         if (hi - lo > 65535) col16 = false;
       }
       const size_t n_ent = (size_t)quads * 256;
+      int n_pattern_slices = 0;
+      for (int32_t v : spat) n_pattern_slices += v >= 0;
       std::vector<double> v2(val8 ? 0 : n_ent, 0.0);
       std::vector<uint8_t> v1(val8 ? n_ent : 0, 0);
       std::vector<int32_t> c4(col16 ? 0 : n_ent, 0);
@@ -285,12 +320,22 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
           const int64_t r2 = sidx * 64 + lane;
           const int64_t k0 = r2 < n_rows ? rowptr[r2] : 0, len = r2 < n_rows ? rowptr[r2 + 1] - k0 : 0;
           const int32_t padcol = r2 < std::min(n_rows, n_cols) ? (int32_t)r2 : sbase[(size_t)sidx];
+          const int pidx = spat[(size_t)sidx];
+          int64_t kk = 0;  // next CSR entry of this row (pattern slices walk the pattern positions)
           for (int64_t j = 0; j < 4 * nq; ++j) {
             const int64_t qq = q0 + j / 4, e = j & 3;
             const size_t ov = (size_t)(((2 * qq + (e >> 1)) * 64 + lane) * 2 + (e & 1));  // double2-pair layout
             const size_t oc = (size_t)((qq * 64 + lane) * 4 + e);                          // 4-per-lane layout
-            const int32_t cj = (j < len && !debug_nogather) ? col[k0 + j] : padcol;
-            const double vj = j < len ? val[k0 + j] : 0.0;
+            int32_t cj;
+            double vj;
+            if (pidx >= 0) {
+              const auto &dl = patterns[(size_t)pidx];
+              if (j < (int64_t)dl.size() && kk < len && col[k0 + kk] - r2 == dl[(size_t)j]) { cj = col[k0 + kk]; vj = val[k0 + kk]; ++kk; }
+              else { cj = (int32_t)(j < (int64_t)dl.size() ? r2 + dl[(size_t)j] : r2); vj = 0.0; }
+            } else {
+              cj = (j < len && !debug_nogather) ? col[k0 + j] : padcol;
+              vj = j < len ? val[k0 + j] : 0.0;
+            }
             if (val8) { uint64_t bits; std::memcpy(&bits, &vj, 8); v1[oc] = (uint8_t)code_of.at(bits); }
             else v2[ov] = vj;
             if (col16) c2[oc] = (uint16_t)(cj - sbase[(size_t)sidx]);
@@ -312,6 +357,18 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       HIPC(hipMemcpyAsync(m.sell_cols, col16 ? (const void *)c2.data() : (const void *)c4.data(), cbytes, hipMemcpyHostToDevice, ctx->stream));
       HIPC(hipStreamSynchronize(ctx->stream));
       m.val8 = val8; m.col16 = col16;
+      if (n_pattern_slices > 0) {
+        std::vector<int32_t> table(patterns.size() * 32, 0);
+        for (size_t pi = 0; pi < patterns.size(); ++pi)
+          for (size_t j = 0; j < 32; ++j) table[pi * 32 + j] = j < patterns[pi].size() ? patterns[pi][j] : 0;  // padding: own row, value +0.0
+        HIPC(hipMalloc(&m.sell_spat, sizeof(int32_t) * spat.size()));
+        HIPC(hipMalloc(&m.sell_pat, sizeof(int32_t) * table.size()));
+        HIPC(hipMemcpyAsync(m.sell_spat, spat.data(), sizeof(int32_t) * spat.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipMemcpyAsync(m.sell_pat, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        m.n_patterns = (int)patterns.size();
+        m.n_pattern_slices = n_pattern_slices;
+      }
       m.sell = true;
       m.n_slices = (int)n_slices;
       m.sell_quads = quads;
@@ -325,8 +382,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
     }
   }
   if (std::getenv("GMG_DEBUG_UPLOAD"))
-    std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d\n", (long long)n_rows,
-                 (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid);
+    std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d patterns %d pattern_slices %d/%d\n", (long long)n_rows,
+                 (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid, m.n_patterns, m.n_pattern_slices, m.n_slices);
   return GMG_OK;
 }
 
@@ -362,7 +419,7 @@ int alloc_vec(gmg_context *ctx, double **p, int64_t n) {
 template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
-    SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.n_slices, (int)m.n_rows, a};
+    SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
     if (m.val8 && m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
     else if (m.val8) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
     else if (m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);

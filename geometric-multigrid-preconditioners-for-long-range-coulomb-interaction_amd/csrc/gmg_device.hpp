@@ -292,13 +292,19 @@ __global__ __launch_bounds__(kThreads) void spmv_tile_kernel(SpmvArgs a) {
 //           handful) -> one byte per entry indexing a dictionary that the kernel keeps in LDS
 //   COL16 : every slice's columns lie within 65536 of the slice's smallest column -> 16-bit
 //           offsets from a per-slice base (lattice operators up to ~180^3)
-// so the level-0 lattice streams 3 bytes per nonzero instead of 12.
+//   PATTERN : slices in which every row has the same (column - row) at every entry position --
+//           all the regular part of a lattice; rows that lack a neighbour (domain boundary) get
+//           an explicit +0.0 entry there -- store no columns at all: the kernel forms
+//           row + delta_j from a tiny per-pattern table (wave-uniform scalar loads)
+// so the level-0 lattice streams 1-3 bytes per nonzero instead of 12.
 struct SellArgs {
   const int32_t *qptr;   // n_slices + 1, in quads
   const int32_t *sbase;  // COL16: smallest column of each slice
   const void *vals;      // VAL8: uchar4[quads * 64]        else double2[2 * quads * 64]
   const void *cols;      // COL16: ushort4[quads * 64]      else int4[quads * 64]
   const double *dict;    // VAL8: 256 doubles
+  const int32_t *spat;   // per slice: column-pattern id, -1 = columns come from the stream (may be null)
+  const int32_t *pat;    // [n_patterns][32]: column - row of every entry position of a pattern slice
   int n_slices;
   int n_rows;
   SpmvArgs a;  // vectors, epilogue operands, CG state (rowptr/col/val unused)
@@ -352,6 +358,12 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
     int s = s0;
     int qe = sa.qptr[s0 + 1];  // end of the current slice
     int base = COL16 ? sa.sbase[s0] : 0;
+    // column-pattern bookkeeping (all wave-uniform): pattern of the current / next slice, first
+    // quad of the current slice, end of the next slice (to classify the quad prefetched 2 ahead)
+    int qb = q;
+    int pid = sa.spat ? sa.spat[s0] : -1;
+    int pid_next = (sa.spat && s0 + 1 < s1) ? sa.spat[s0 + 1] : -1;
+    int qe_next = (s0 + 1 < s1) ? sa.qptr[s0 + 2] : Q1;
     double acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
     using ColT = typename std::conditional<COL16, ushort4, int4>::type;
     const ColT *cbase = reinterpret_cast<const ColT *>(sa.cols) + lane;
@@ -361,7 +373,9 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
     ColT ca{}, cb{}, cc{};
 
     auto load_quad = [&](SellVals<VAL8> &V, ColT &C, int Q) {
-      C = cbase[(size_t)Q * 64];
+      // pattern slices need no column stream; a quad beyond the next slice is loaded to be safe
+      const bool patterned = Q < qe ? pid >= 0 : (Q < qe_next ? pid_next >= 0 : false);
+      if (!patterned) C = cbase[(size_t)Q * 64];
       if constexpr (VAL8) V.code = kbase[(size_t)Q * 64];
       else { V.v0 = vbase[(size_t)(2 * Q) * 64]; V.v1 = vbase[(size_t)(2 * Q + 1) * 64]; }
     };
@@ -384,7 +398,11 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
       }
       ++s;
       if (s < s1) {
+        qb = qe;
         qe = sa.qptr[s + 1];
+        pid = pid_next;
+        pid_next = (sa.spat && s + 1 < s1) ? sa.spat[s + 1] : -1;
+        qe_next = (s + 1 < s1) ? sa.qptr[s + 2] : Q1;
         if constexpr (COL16) base = sa.sbase[s];
         acc = (a.init && s * 64 + lane < sa.n_rows) ? a.init[s * 64 + lane] : 0.0;
       }
@@ -392,7 +410,15 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
     // gathers of the current quad first, THEN the prefetch two quads ahead: the in-order vmcnt
     // wait for the gathers leaves the younger stream loads in flight
     auto step = [&](SellVals<VAL8> &V, ColT &C, SellVals<VAL8> &NV, ColT &NC) {
-      const double x0_ = X(base + (int)C.x), x1_ = X(base + (int)C.y), x2_ = X(base + (int)C.z), x3_ = X(base + (int)C.w);
+      int c0, c1, c2, c3;
+      if (pid >= 0) {
+        const int4 dl = *reinterpret_cast<const int4 *>(sa.pat + (size_t)pid * 32 + 4 * (q - qb));
+        const int row = s * 64 + lane;
+        c0 = row + dl.x; c1 = row + dl.y; c2 = row + dl.z; c3 = row + dl.w;
+      } else {
+        c0 = base + (int)C.x; c1 = base + (int)C.y; c2 = base + (int)C.z; c3 = base + (int)C.w;
+      }
+      const double x0_ = X(c0), x1_ = X(c1), x2_ = X(c2), x3_ = X(c3);
       double w0, w1, w2, w3;
       if constexpr (VAL8) { w0 = dict[V.code.x]; w1 = dict[V.code.y]; w2 = dict[V.code.z]; w3 = dict[V.code.w]; }
       else { w0 = V.v0.x; w1 = V.v0.y; w2 = V.v1.x; w3 = V.v1.y; }
