@@ -1094,6 +1094,15 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     ctx->stats.spmv0_rows = n_rows;
     ctx->stats.spmv0_nnz = rowptr[n_rows];
     ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) : 0;
+    if (L.A.sell) {
+      const double frac_stream = L.A.n_slices ? 1.0 - (double)L.A.n_pattern_slices / L.A.n_slices : 1.0;
+      const int64_t ent = L.A.sell_quads * 256;
+      ctx->stats.spmv0_matrix_bytes = ent * (L.A.val8 ? 1 : 8) + (int64_t)(frac_stream * (double)ent * (L.A.col16 ? 2 : 4)) + 8 * (int64_t)L.A.n_slices;
+    } else {
+      ctx->stats.spmv0_matrix_bytes = 12 * rowptr[n_rows] + 4 * (n_rows + 1);
+    }
+    ctx->stats.spmv0_pattern_slices = L.A.n_pattern_slices;
+    ctx->stats.spmv0_slices = L.A.n_slices;
     ctx->last_coarse_iters = 0;
   }
   HIPC(hipStreamSynchronize(ctx->stream));
@@ -1524,9 +1533,11 @@ int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_
 
 int gmg_stats_reset(gmg_context *ctx) {
   if (!ctx) return GMG_ERR_INVALID;
-  const int64_t r = ctx->stats.spmv0_rows, z = ctx->stats.spmv0_nnz, v = ctx->stats.coarse_variant, y = ctx->stats.spmv0_layout;
+  const gmg_stats keep = ctx->stats;
   ctx->stats = gmg_stats{};
-  ctx->stats.spmv0_rows = r; ctx->stats.spmv0_nnz = z; ctx->stats.coarse_variant = v; ctx->stats.spmv0_layout = y;
+  ctx->stats.spmv0_rows = keep.spmv0_rows; ctx->stats.spmv0_nnz = keep.spmv0_nnz; ctx->stats.coarse_variant = keep.coarse_variant;
+  ctx->stats.spmv0_layout = keep.spmv0_layout; ctx->stats.spmv0_matrix_bytes = keep.spmv0_matrix_bytes;
+  ctx->stats.spmv0_pattern_slices = keep.spmv0_pattern_slices; ctx->stats.spmv0_slices = keep.spmv0_slices;
   return GMG_OK;
 }
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out) {

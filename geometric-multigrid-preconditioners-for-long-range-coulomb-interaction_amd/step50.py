@@ -47,6 +47,8 @@ def load(build_if_missing: bool = False):
         _lib.step50_gmg_context.restype = C.c_void_p
         for f in ("step50_n_atoms", "step50_copy_indices_size", "step50_n_dofs"):
             getattr(_lib, f).restype = C.c_int64
+        # host-side setup threads: a GPU box shares its cores between GPUs (16 per GPU)
+        _lib.step50_set_threads(C.c_int(max(1, min(16, os.cpu_count() or 1))))
     return _lib
 
 
