@@ -29,7 +29,7 @@ SYMBOLS = [
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
     "gmg_comm_unique_id", "gmg_comm_init", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
     "gmg_vec_allgather",
-    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_calibrate_hbm", "gmg_charge_density",
+    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density",
 ]
 
 
@@ -292,6 +292,7 @@ class Context:
         self._chk(self.L.gmg_calibrate_hbm(self.h, C.c_int64(n_bytes), C.c_int(reps), C.byref(r), C.byref(c)))
         return r.value, c.value
 
-    def set_tuning(self, coarse_chunk=0, use_graph=0, cg_variant=0, ssor_blocks=0):
-        flags = (use_graph & 1) | ((cg_variant & 3) << 4) | (int(ssor_blocks) << 8)
-        self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(flags)))
+    def set_tuning(self, coarse_chunk=0, cg_variant=0, ssor_blocks=0):
+        self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(cg_variant)))
+        if ssor_blocks:
+            self._chk(self.L.gmg_set_ssor_blocks(self.h, C.c_int(ssor_blocks)))

@@ -108,7 +108,6 @@ struct gmg_context {
   double *scal_host = nullptr;                  // pinned, 8 doubles
   // tuning / measurement
   int coarse_chunk = 0;
-  int use_graph = 0;
   int ssor_blocks = 1;  // 1 = exact sequential SGS; B > 1 = block Jacobi of SGS (the reference on B ranks)
   int cg_variant = 0;  // 0 auto, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration
   int last_coarse_iters = 0;
@@ -1591,12 +1590,16 @@ int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_
   return GMG_OK;
 }
 
-int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph) {
-  if (!ctx) return GMG_ERR_INVALID;
+int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant) {
+  if (!ctx || coarse_chunk < 0 || cg_variant < 0 || cg_variant > 2) return GMG_ERR_INVALID;
   ctx->coarse_chunk = coarse_chunk;
-  ctx->use_graph = use_graph & 1;
-  ctx->cg_variant = (use_graph >> 4) & 3;
-  if ((use_graph >> 8) > 0) ctx->ssor_blocks = use_graph >> 8;  // bits 8..: SSOR blocks (before gmg_set_level_matrix)  // bits 4-5: coarse-CG variant (0 auto, 1 fused, 2 unfused)
+  ctx->cg_variant = cg_variant;
+  return GMG_OK;
+}
+
+int gmg_set_ssor_blocks(gmg_context *ctx, int n_blocks) {
+  if (!ctx || n_blocks < 1) return GMG_ERR_INVALID;
+  ctx->ssor_blocks = n_blocks;
   return GMG_OK;
 }
 

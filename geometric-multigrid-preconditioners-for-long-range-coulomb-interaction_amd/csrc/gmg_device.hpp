@@ -347,9 +347,14 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
   const int s1 = __builtin_amdgcn_readfirstlane(min(s0 + per_wave, x1));
   double dot_acc = 0.0;
 
+  // gathers go through a buffer descriptor: 32-bit element offsets instead of 64-bit address
+  // arithmetic per lane (the compressed kernel is VALU / TA-issue bound, not HBM bound)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.x), 0, 0x7FFFFFFF, 0x00020000);
   auto X = [&](int c) -> double {
-    if constexpr (XFORM) return beta * a.x[c] - a.g[c];
-    else return a.x[c];
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rx, c << 3, 0, 0);
+    const double xv = __builtin_bit_cast(double, raw);
+    if constexpr (XFORM) return beta * xv - a.g[c];
+    else return xv;
   };
 
   if (s0 < s1) {

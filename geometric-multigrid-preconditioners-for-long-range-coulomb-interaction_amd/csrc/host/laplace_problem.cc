@@ -1006,7 +1006,7 @@ int LaplaceProblem<dim>::upload() {
     GMGC(gmg_reset(gmg, L));  // the context may have been created early (charge densities) with 1 level
   }
   operators_uploaded = true;
-  GMGC(gmg_set_tuning(gmg, 0, par.ssor_blocks << 8));  // before the level matrices: sizes the SGS schedule
+  GMGC(gmg_set_ssor_blocks(gmg, par.ssor_blocks));  // before the level matrices: sizes the SGS schedule
   const CSRMatrix &S = system_matrix;
   if (distributed) {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),

@@ -181,13 +181,15 @@ int gmg_set_profiling(gmg_context *ctx, int sample_every);
 /* streaming-read and copy bandwidth of this device (GB/s) on n_bytes per array: the measured
  * ceiling bench.py prints beside the 8 TB/s spec peak.                                    */
 int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_gbps, double *copy_gbps);
-/* tuning knobs (0 keeps the default): iterations enqueued between host convergence checks;
- * flags bit 0: hipGraph replay of the coarse-CG chunk, bits 4-5: coarse-CG variant
- * (0 auto by size, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration), bits 8..: number of
- * SSOR blocks B (1 = exact sequential sweep; B > 1 = what the reference's smoother does on B
- * MPI ranks: SGS inside a block of rows, couplings between blocks dropped); call before the
- * level matrices are set.                                                                  */
-int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int use_graph);
+/* tuning knobs: coarse_chunk = iterations enqueued between host convergence checks (0 = predicted
+ * from the previous solve); cg_variant = 0 auto by size, 1 fused two-kernel iteration (SpMV also
+ * forms d = beta d - g), 2 three-kernel iteration.                                          */
+int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant);
+/* SSOR blocks B: 1 = exact sequential sweep (the reference on one rank); B > 1 = what the
+ * reference's smoother does on B MPI ranks: symmetric Gauss-Seidel inside each block of
+ * consecutive rows, couplings between blocks dropped (Ifpack's rank-local matrix).  Call before
+ * the level matrices are set.                                                              */
+int gmg_set_ssor_blocks(gmg_context *ctx, int n_blocks);
 
 #ifdef __cplusplus
 }
