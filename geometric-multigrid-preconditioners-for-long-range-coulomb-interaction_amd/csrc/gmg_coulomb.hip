@@ -42,6 +42,9 @@ struct DevCSR {
   void *sell_cols = nullptr;     // ushort4 offsets (COL16) or int4 columns
   double *sell_dict = nullptr;   // VAL8: 256 doubles
   int32_t *sell_spat = nullptr, *sell_pat = nullptr;  // column-pattern ids per slice / pattern table
+  int sellp_pid = -1, sellp_centre[9] = {};  // the nine-runs-of-three pattern served by spmv_sellp_kernel
+  int32_t *sellp_wave_ptr = nullptr;          // slice range of every wave of spmv_sellp_kernel
+  bool use_sellp = false;
   int n_patterns = 0, n_pattern_slices = 0;
   bool val8 = false, col16 = false;
   int n_slices = 0, sell_grid = 0;
@@ -170,12 +173,14 @@ void free_csr(DevCSR &m) {
   if (m.val) (void)hipFree(m.val);
   if (m.tile_row) (void)hipFree(m.tile_row);
   if (m.slice_ptr) (void)hipFree(m.slice_ptr);
+  if (m.sellp_wave_ptr) (void)hipFree(m.sellp_wave_ptr);
   if (m.slice_base) (void)hipFree(m.slice_base);
   if (m.sell_vals) (void)hipFree(m.sell_vals);
   if (m.sell_cols) (void)hipFree(m.sell_cols);
   if (m.sell_dict) (void)hipFree(m.sell_dict);
   if (m.sell_spat) (void)hipFree(m.sell_spat);
   if (m.sell_pat) (void)hipFree(m.sell_pat);
+
   free_halo(m.halo);
   m = DevCSR();
 }
@@ -367,6 +372,25 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
         HIPC(hipStreamSynchronize(ctx->stream));
         m.n_patterns = (int)patterns.size();
         m.n_pattern_slices = n_pattern_slices;
+        // the most frequent pattern made of nine runs of three consecutive columns (the x-1, x, x+1
+        // neighbours of a 27-point lattice row) is served by spmv_sellp_kernel
+        std::vector<size_t> uses(patterns.size(), 0);
+        for (size_t sl = 0; sl < n_slices; ++sl)
+          if (spat[sl] >= 0) ++uses[(size_t)spat[sl]];
+        size_t n_run_slices = 0;
+        m.sellp_pid = -1;
+        for (size_t pi = 0; pi < patterns.size(); ++pi) {
+          const auto &dl = patterns[pi];
+          bool ok = dl.size() == 27;
+          for (size_t j = 0; ok && j < dl.size(); j += 3) ok = dl[j + 1] == dl[j] + 1 && dl[j + 2] == dl[j] + 2;
+          if (!ok || uses[pi] <= n_run_slices) continue;
+          n_run_slices = uses[pi];
+          m.sellp_pid = (int)pi;
+          for (size_t u = 0; u < 9; ++u) m.sellp_centre[u] = dl[3 * u + 1];
+        }
+        const char *no_p = std::getenv("GMG_DISABLE_SELLP");
+        // worth it when (nearly) the whole operator is patterned: the streamed slices of this kernel are not pipelined
+        m.use_sellp = val8 && !(no_p && no_p[0] == '1') && n_run_slices * 10 >= n_slices * 9;
       }
       m.sell = true;
       m.n_slices = (int)n_slices;
@@ -374,6 +398,35 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       // one wave per >= 1 slice; at most 1024 workgroups (4 per CU)
       const int per_xcd = (int)((n_slices + 7) / 8);
       m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
+      if (const char *g = std::getenv("GMG_SELL_GRID")) m.sell_grid = std::max(8, std::atoi(g) / 8 * 8);
+      if (m.use_sellp) {
+        // 7 workgroups per CU are resident at the kernel's 72 registers: one round
+        if (!std::getenv("GMG_SELL_GRID")) m.sell_grid = std::min(m.sell_grid, 256 * 7);
+        // contiguous slice ranges per wave, balanced by cost: a streamed slice (one memory round trip
+        // per quad) costs about four pattern slices
+        double other_cost = 4.0;
+        if (const char *c = std::getenv("GMG_SELLP_COST")) other_cost = std::atof(c);
+        const int n_waves = m.sell_grid * 4;
+        std::vector<double> cost(n_slices + 1, 0.0);
+        for (size_t sl = 0; sl < n_slices; ++sl)
+          cost[sl + 1] = cost[sl] + (spat[sl] == m.sellp_pid ? 1.0 : std::max(0.25, other_cost * (double)(sp[sl + 1] - sp[sl]) / 7.0));
+        std::vector<int32_t> wp((size_t)n_waves + 1, 0);
+        size_t sl = 0;
+        int longest = 0;
+        for (int wv = 1; wv <= n_waves; ++wv) {
+          const double target = cost[n_slices] * (double)wv / (double)n_waves;
+          while (sl < n_slices && cost[sl + 1] <= target + 1e-9) ++sl;
+          if (wv == n_waves) sl = n_slices;
+          wp[(size_t)wv] = (int32_t)sl;
+          longest = std::max(longest, wp[(size_t)wv] - wp[(size_t)wv - 1]);
+        }
+        if (longest > 64) m.use_sellp = false;  // slice metadata lives in the 64 lanes
+        else {
+          HIPC(hipMalloc(&m.sellp_wave_ptr, sizeof(int32_t) * wp.size()));
+          HIPC(hipMemcpyAsync(m.sellp_wave_ptr, wp.data(), sizeof(int32_t) * wp.size(), hipMemcpyHostToDevice, ctx->stream));
+          HIPC(hipStreamSynchronize(ctx->stream));
+        }
+      }
       if (!keep_csr) {  // the CSR copy is only kept where the SGS sweeps need it (levels >= 1)
         (void)hipFree(m.col); (void)hipFree(m.val); (void)hipFree(m.tile_row);
         m.col = nullptr; m.val = nullptr; m.tile_row = nullptr;
@@ -419,6 +472,13 @@ template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
     SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
+    if constexpr (CG != 1) if (m.use_sellp) {
+      SellPatArgs pa{};
+      pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
+      for (int u = 0; u < 9; ++u) pa.centre[u] = m.sellp_centre[u];
+      hipLaunchKernelGGL((spmv_sellp_kernel<MODE, CG>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, pa);
+      return m.sell_grid;
+    }
     if (m.val8 && m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
     else if (m.val8) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
     else if (m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);

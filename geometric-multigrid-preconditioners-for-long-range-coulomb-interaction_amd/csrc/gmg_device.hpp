@@ -449,6 +449,163 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
   }
 }
 
+// ---------------------------------------------------------------- SELL-64 pattern kernel (lattice fast path)
+//
+// The texture-address unit of a CU retires one vector load instruction per ~16 cycles whatever
+// its width or the number of active lanes (tools/micro/ta_probe.hip), so the per-entry gathers of
+// the kernel above cost 27 x 16 cycles per slice.  In a pattern slice lane L needs x[r0 + L + delta_j];
+// for the 27-point lattice row the deltas come as nine runs (x-1, x, x+1).  This kernel reads one
+// 16-byte pair {x[c], x[c+1]} per lane and run (c = row + centre offset), gets x[c-1] from the
+// neighbouring lane with a DPP wave shift, and fetches the one element left of the wave with a
+// scalar load: nine vector loads per slice instead of 27.  Products are still added in CSR order
+// with the exact dictionary values, so the result is bit-identical.  Slices with any other pattern
+// (the boundary of the numbering) take a plain streamed loop.
+struct SellPatArgs {
+  SellArgs sa;
+  const int32_t *wave_ptr;  // [gridDim.x * 4 + 1]: slice range of every wave (XCD-major, balanced by slice cost on the host)
+  int pid0;        // the pattern served by the fast path
+  int centre[9];   // column offset (relative to the row) of the centre entry of each of its nine runs
+  int col16;       // layout of the column stream used by the other slices
+};
+
+// lane L <- value of lane L-1; lane 0 <- edge (wave-uniform)
+__device__ __forceinline__ double shift_in_from_left(double v, double edge) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_double(double v, int l) {  // l: wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int MODE, int CG>
+__global__ __launch_bounds__(kThreads, 7) void spmv_sellp_kernel(SellPatArgs pa) {
+  static_assert(CG != 1, "the pattern kernel serves the plain and the unfused-CG products");
+  __shared__ double red[4];
+  __shared__ double dict[256];
+  const SellArgs &sa = pa.sa;
+  const SpmvArgs &a = sa.a;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if constexpr (CG == 2) {
+    if (a.st->done) return;
+  }
+  // consecutive workgroups go to consecutive XCDs: wave index = (xcd, workgroup within the xcd, wave), so
+  // that every XCD (own L2) walks one contiguous range of slices
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
+  const int w = (xcd * nb + lb) * 4 + wid;
+  const int s0 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w]);
+  const int s1 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w + 1]);  // s1 - s0 <= 64 (host)
+  // slice metadata of the whole wave in one round trip, together with the dictionary: lane i <-> slice s0 + i
+  int m_qb = 0, m_qe = 0, m_pid = -1;
+  if (s0 + lane < s1) {
+    m_qb = sa.qptr[s0 + lane];
+    m_qe = sa.qptr[s0 + lane + 1];
+    m_pid = sa.spat[s0 + lane];
+  }
+  dict[threadIdx.x] = sa.dict[threadIdx.x];
+  __syncthreads();
+  double dot_acc = 0.0;
+  const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
+  const double *xb[9];
+  int my_centre = pa.centre[0];  // lanes 0..8 <-> runs (lanes >= 9 repeat run 0: harmless, in range)
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    xb[u] = a.x + pa.centre[u];
+    if (lane == u) my_centre = pa.centre[u];
+  }
+
+  double carry[9];  // wave-uniform
+  bool have_carry = false;
+  for (int s = s0; s < s1; ++s) {
+    const int i = s - s0;
+    const int pid = __builtin_amdgcn_readlane(m_pid, i);
+    const int qb = __builtin_amdgcn_readlane(m_qb, i);
+    const int row = s * 64 + lane;
+    const bool valid = row < sa.n_rows;
+    double acc = (a.init && valid) ? a.init[row] : 0.0;
+    double self = 0.0;      // x[row] for the CG dot product: the centre of the middle run when that is the diagonal
+    bool have_self = false;
+    if (pid == pa.pid0) {
+      // ---- nine runs of three: all 64 rows exist; 7 quads of codes per lane
+      double2 p[9];
+      uchar4 k[7];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) p[u] = *reinterpret_cast<const double2 *>(xb[u] + row);  // 8-byte aligned 16-byte load
+#pragma unroll
+      for (int u = 0; u < 7; ++u) k[u] = kbase[(size_t)(qb + u) * 64];
+      if (!have_carry) {  // first slice of the wave (or after a streamed slice): lane u fetches the element left of run u
+        const double e = a.x[(size_t)s * 64 - 1 + my_centre];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) carry[u] = lane_double(e, u);
+      }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const double left = shift_in_from_left(p[u].x, carry[u]);
+        const uchar4 w0 = k[(3 * u) >> 2], w1 = k[(3 * u + 1) >> 2], w2 = k[(3 * u + 2) >> 2];
+        const int e0 = (3 * u) & 3, e1 = (3 * u + 1) & 3, e2 = (3 * u + 2) & 3;
+        const int c0 = e0 == 0 ? w0.x : e0 == 1 ? w0.y : e0 == 2 ? w0.z : w0.w;
+        const int c1 = e1 == 0 ? w1.x : e1 == 1 ? w1.y : e1 == 2 ? w1.z : w1.w;
+        const int c2 = e2 == 0 ? w2.x : e2 == 1 ? w2.y : e2 == 2 ? w2.z : w2.w;
+        acc += dict[c0] * left;
+        acc += dict[c1] * p[u].x;
+        acc += dict[c2] * p[u].y;
+      }
+      if (pa.centre[4] == 0) { self = p[4].x; have_self = true; }
+      // lane 63 of this slice is the left neighbour of lane 0 of the next one
+#pragma unroll
+      for (int u = 0; u < 9; ++u) carry[u] = lane_double(p[u].x, 63);
+      have_carry = true;
+    } else {
+      have_carry = false;
+      // ---- any other slice: quad by quad, the columns and codes of the next quad in flight while
+      // the gathers of this one are summed
+      const int qe = __builtin_amdgcn_readlane(m_qe, i);
+      const int base = pa.col16 ? sa.sbase[s] : 0;
+      const int32_t *pat = pid >= 0 ? sa.pat + (size_t)pid * 32 : nullptr;
+      auto cols_of = [&](int q, int (&c)[4]) {
+        if (pat) {
+          const int j = (q - qb) * 4;
+          c[0] = row + pat[j]; c[1] = row + pat[j + 1]; c[2] = row + pat[j + 2]; c[3] = row + pat[j + 3];
+        } else if (pa.col16) {
+          const ushort4 C = (reinterpret_cast<const ushort4 *>(sa.cols) + lane)[(size_t)q * 64];
+          c[0] = base + C.x; c[1] = base + C.y; c[2] = base + C.z; c[3] = base + C.w;
+        } else {
+          const int4 C = (reinterpret_cast<const int4 *>(sa.cols) + lane)[(size_t)q * 64];
+          c[0] = C.x; c[1] = C.y; c[2] = C.z; c[3] = C.w;
+        }
+      };
+      int c[4] = {0, 0, 0, 0};
+      uchar4 kq{0, 0, 0, 0};
+      if (qb < qe) { kq = kbase[(size_t)qb * 64]; cols_of(qb, c); }
+      for (int q = qb; q < qe; ++q) {
+        const double v0 = a.x[c[0]], v1 = a.x[c[1]], v2 = a.x[c[2]], v3 = a.x[c[3]];
+        const uchar4 k0 = kq;
+        if (q + 1 < qe) { kq = kbase[(size_t)(q + 1) * 64]; cols_of(q + 1, c); }
+        acc += dict[k0.x] * v0; acc += dict[k0.y] * v1; acc += dict[k0.z] * v2; acc += dict[k0.w] * v3;
+      }
+    }
+    if (valid) {
+      const int r = row;
+      if constexpr (CG == 2) {
+        if (!have_self) self = a.x[r];
+        a.y[r] = acc; dot_acc += self * acc;
+      } else if constexpr (MODE == kStore) a.y[r] = acc;
+      else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;
+      else if constexpr (MODE == kAddTo) a.y[r] = a.b[r] + acc;
+      else if constexpr (MODE == kJacobi) a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
+      else if constexpr (MODE == kCheb) {
+        const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
+        a.w[r] = wn; a.y[r] = a.x[r] + wn;
+      }
+    }
+  }
+  if constexpr (CG != 0) {
+    const double sblock = block_sum(dot_acc, red);
+    if (threadIdx.x == 0) a.part_out[blockIdx.x] = sblock;
+  }
+}
+
 // Distributed coarse CG: opens the iteration and forms d = beta d - g on the owned range;
 // the ghost entries of d arrive by halo exchange before the SpMV (CG = 2).
 struct CGDirArgs {
