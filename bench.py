@@ -144,6 +144,8 @@ def main():
         val8, col16 = bool(lay >= 1 and (lay - 1) & 2), bool(lay >= 1 and (lay - 1) & 4)
         tmpl = f"0, {1 if fused else 2}" + (f", {'true' if val8 else 'false'}, {'true' if col16 else 'false'}" if lay >= 1 else "")
         kname = ("spmv_sell_kernel" if lay >= 1 else "spmv_tile_kernel") + f"<{tmpl}>"
+        if lay >= 1 and (lay - 1) & 8 and not fused:  # lattice operator: pattern-run kernel (pair loads + lane shift)
+            kname = "spmv_sellp_kernel<0, 2>"
         # bytes the internal layout actually streams: SELL-64 pads rows to a multiple of 4 entries;
         # values are 1-byte dictionary codes (val8) or fp64, columns 2-byte offsets (col16) or int32
         # (pattern slices stream no columns at all); the library reports the exact size of those streams
@@ -154,7 +156,8 @@ def main():
                 "note": "achieved = ALGORITHMIC CSR bytes (12 nnz + 4 (N+1) + 16 N [+16 N fused]) / launch time; the kernel "
                         "streams a compressed SELL-64 copy (layout_bytes_per_launch; traffic = PMC-measured HBM bytes), so "
                         "achieved may exceed the HBM peak; achieved_layout = bytes of that layout / time is the figure "
-                        "bounded by the 8 TB/s roofline (the compressed kernel is gather-issue bound, not HBM bound)",
+                        "bounded by the 8 TB/s roofline (the compressed kernels are bound by vector-load issue and VALU work per "
+                        "slice, not by HBM: DESIGN.md section 3)",
                 "layout_bytes_per_launch": int(moved), "pattern_slices": [int(st.spmv0_pattern_slices), int(st.spmv0_slices)], "achieved_layout": round(moved / t_k / 1e9, 1),
                 "frac_layout": round(moved / t_k / 1e9 / HBM_PEAK_GBS, 4), "measured_stream_read_GBps": round(hbm_read, 1),
                 "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),

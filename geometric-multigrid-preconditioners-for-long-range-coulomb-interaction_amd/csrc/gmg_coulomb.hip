@@ -400,8 +400,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
       if (const char *g = std::getenv("GMG_SELL_GRID")) m.sell_grid = std::max(8, std::atoi(g) / 8 * 8);
       if (m.use_sellp) {
-        // 7 workgroups per CU are resident at the kernel's 72 registers: one round
-        if (!std::getenv("GMG_SELL_GRID")) m.sell_grid = std::min(m.sell_grid, 256 * 7);
+        // as many workgroups as are resident at the kernel's register budget: one round
+        if (!std::getenv("GMG_SELL_GRID")) m.sell_grid = std::min(m.sell_grid, 256 * kSellpWaves);
         // contiguous slice ranges per wave, balanced by cost: a streamed slice (one memory round trip
         // per quad) costs about four pattern slices
         double other_cost = 4.0;
@@ -1152,7 +1152,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
     ctx->stats.spmv0_rows = n_rows;
     ctx->stats.spmv0_nnz = rowptr[n_rows];
-    ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) : 0;
+    ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) + (L.A.use_sellp ? 8 : 0) : 0;
     if (L.A.sell) {
       const double frac_stream = L.A.n_slices ? 1.0 - (double)L.A.n_pattern_slices / L.A.n_slices : 1.0;
       const int64_t ent = L.A.sell_quads * 256;

@@ -479,8 +479,10 @@ __device__ __forceinline__ double lane_double(double v, int l) {  // l: wave-uni
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+constexpr int kSellpWaves = 6;  // resident waves per SIMD (= workgroups per CU) the register budget of the kernel is set for
+
 template <int MODE, int CG>
-__global__ __launch_bounds__(kThreads, 7) void spmv_sellp_kernel(SellPatArgs pa) {
+__global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellPatArgs pa) {
   static_assert(CG != 1, "the pattern kernel serves the plain and the unfused-CG products");
   __shared__ double red[4];
   __shared__ double dict[256];
@@ -539,17 +541,22 @@ __global__ __launch_bounds__(kThreads, 7) void spmv_sellp_kernel(SellPatArgs pa)
 #pragma unroll
         for (int u = 0; u < 9; ++u) carry[u] = lane_double(e, u);
       }
+      // dictionary values of run u+1 are looked up before the products of run u are summed
+      auto code_at = [&](int j) -> int {
+        const uchar4 w = k[j >> 2];
+        const int e = j & 3;
+        return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w;
+      };
+      double w0 = dict[code_at(0)], w1 = dict[code_at(1)], w2 = dict[code_at(2)];
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+        if (u < 8) { n0 = dict[code_at(3 * u + 3)]; n1 = dict[code_at(3 * u + 4)]; n2 = dict[code_at(3 * u + 5)]; }
         const double left = shift_in_from_left(p[u].x, carry[u]);
-        const uchar4 w0 = k[(3 * u) >> 2], w1 = k[(3 * u + 1) >> 2], w2 = k[(3 * u + 2) >> 2];
-        const int e0 = (3 * u) & 3, e1 = (3 * u + 1) & 3, e2 = (3 * u + 2) & 3;
-        const int c0 = e0 == 0 ? w0.x : e0 == 1 ? w0.y : e0 == 2 ? w0.z : w0.w;
-        const int c1 = e1 == 0 ? w1.x : e1 == 1 ? w1.y : e1 == 2 ? w1.z : w1.w;
-        const int c2 = e2 == 0 ? w2.x : e2 == 1 ? w2.y : e2 == 2 ? w2.z : w2.w;
-        acc += dict[c0] * left;
-        acc += dict[c1] * p[u].x;
-        acc += dict[c2] * p[u].y;
+        acc += w0 * left;
+        acc += w1 * p[u].x;
+        acc += w2 * p[u].y;
+        w0 = n0; w1 = n1; w2 = n2;
       }
       if (pa.centre[4] == 0) { self = p[4].x; have_self = true; }
       // lane 63 of this slice is the left neighbour of lane 0 of the next one

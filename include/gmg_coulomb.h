@@ -170,7 +170,7 @@ typedef struct gmg_stats {
   int64_t cgupd_samples;
   double cgupd_ms_total;
   int64_t coarse_variant;       /* 1 = fused (SpMV + direction update), 2 = unfused, of the last solve */
-  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) */
+  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) */
   int64_t spmv0_matrix_bytes;   /* bytes of the level-0 operator one SpMV streams in its device layout */
   int64_t spmv0_pattern_slices, spmv0_slices; /* slices served by a column pattern / all slices */
 } gmg_stats;

@@ -47,9 +47,13 @@ def banded(n, width, rng, distinct=None, spread=1):
 
 
 @pytest.mark.parametrize("case,expect", [
-    ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
+    ("val8_col16_runs", 1 + 2 + 4 + 8), ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
 ])
-def test_sell_variants_bit_exact(case, expect):
+def test_sell_variants_bit_exact(case, expect, monkeypatch):
+    """27 consecutive columns per row are nine runs of three: with 8-bit value codes that operator goes to
+    the pattern-run kernel (layout bit 8) unless the diagnostic switch keeps it on the per-entry kernel."""
+    if case == "val8_col16":
+        monkeypatch.setenv("GMG_DISABLE_SELLP", "1")
     rng = np.random.default_rng(11)
     n = 5000 + 37  # not a multiple of 64
     distinct = np.array([-1 / 6, -1 / 12, 8 / 3, 0.0, 1.25]) if "val8" in case else None
@@ -160,6 +164,11 @@ def test_full_size_operator_properties(full_size):
         scale = np.abs(A_a).max() + np.abs(A_b).max()
         assert np.abs(A_ab - (2.0 * A_a - 3.0 * A_b)).max() <= 1e-13 * scale * 10          # linearity
         assert abs(ctx.dot(vb, ya) - ctx.dot(va, yb)) <= 1e-11 * abs(ctx.dot(va, ya))        # symmetry
+    # the 121^3 level-0 product (pattern-run kernel, layout bit 8) against the oracle, bit for bit
+    assert (int(ctx.stats().spmv0_layout) - 1) & 8
+    A0 = p.matrix("level", 0)
+    ctx.spmv(0, ya, va)
+    assert np.array_equal(ya.download(), go.spmv(A0, a))
     # residual of the converged solve: |b - A x| <= 1e-8 |b| recomputed with numpy on the host
     h = p.hierarchy()
     x = np.where(h.constrained, 0.0, p.vector("solution"))
