@@ -663,11 +663,14 @@ constexpr int64_t kUnfusedMinRowsDecl = 400000;
 // same number of iterations); while the host waits for a chunk's state, the NEXT chunk is
 // already queued, so the GPU never idles on the host round trip -- iterations enqueued after
 // convergence return at once (the `done` flag, ~1 us each).
+// `later_default`: iterations per follow-up chunk; it only has to outlast the host's poll-and-enqueue
+// round trip (~30 us), so long iterations (large level 0) take short chunks and waste fewer no-ops.
 template <class EnqueueOne>
-int run_cg_chunks(gmg_context *ctx, EnqueueOne enqueue_one) {
+int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
   const int maxit = ctx->coarse_maxit;
-  const int first = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (ctx->last_coarse_iters > 8 ? ctx->last_coarse_iters - 2 : 16);
-  const int later = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : 6;
+  const int last = ctx->last_coarse_iters;
+  const int first = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (last > 8 ? last - (later_default < 6 ? std::max(2, last / 8) : 2) : 16);
+  const int later = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : later_default;
   int launched = 0;
   auto launch_chunk = [&](int n, int slot) -> int {
     for (int q = 0; q < n; ++q) {
@@ -721,7 +724,7 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   int n_part_gg = g_init;
   const int maxit = ctx->coarse_maxit;
   ctx->ev_used = 0; ctx->ev2_used = 0;
-  CHK(run_cg_chunks(ctx, [&](int launched) -> int {
+  CHK(run_cg_chunks(ctx, 6, [&](int launched) -> int {
     const bool odd = launched & 1;
     SpmvArgs a = base_args(A, odd ? ctx->cg_d1 : ctx->cg_d0, ctx->cg_h);
     a.g = ctx->cg_g;

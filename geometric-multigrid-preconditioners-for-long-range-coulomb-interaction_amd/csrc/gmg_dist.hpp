@@ -38,7 +38,7 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
 
   const int maxit = ctx->coarse_maxit;
   ctx->ev_used = 0; ctx->ev2_used = 0;
-  CHK(run_cg_chunks(ctx, [&](int launched) -> int {
+  CHK(run_cg_chunks(ctx, (!ctx->dist && L0.n >= kUnfusedMinRows) ? 3 : 6, [&](int launched) -> int {
     CGDirArgs da{d, ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
     hipLaunchKernelGGL(cg_direction_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, da);
     if (comm && halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");

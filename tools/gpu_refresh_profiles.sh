@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates what profiles/ holds for the current build (run via gpurun, then copy from gpurun_out/):
+#   bench_default.json / bench_atoms8.json   the bench lines (default run incl. cpu_baseline)
+#   kernel_stats.csv                          rocprofv3 --kernel-trace --stats of the default bench command
+#   pmc_traffic_atoms64000.json               FETCH_SIZE / WRITE_SIZE passes (tools/gpu_pmc_traffic.sh)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/refresh
+rm -rf $O; mkdir -p $O
+export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+cd $R
+timeout -k 10 300 python bench.py --workload atoms8 --no-cpu-baseline > $O/bench_atoms8.json 2> $O/bench_atoms8.err || { tail -5 $O/bench_atoms8.err; exit 1; }
+echo "atoms8 done"
+timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 2; }
+echo "default done"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof.log 2>&1 || { tail -5 $O/prof.log; exit 3; }
+cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats.csv && rm -rf $O/prof
+echo "rocprof done"
+cd $R
+bash tools/gpu_pmc_traffic.sh atoms64000 > $O/pmc_traffic.log 2>&1 || { tail -5 $O/pmc_traffic.log; exit 4; }
+cp $R/gpurun_out/pmc_traffic_atoms64000.json $O/
+rm -rf $R/gpurun_out/pmc_traffic
+tail -3 $O/bench_default.json | cut -c1-600
