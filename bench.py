@@ -164,8 +164,11 @@ def main():
                 "launches_sampled": int(st.spmv0_samples)}
         if st.cgupd_samples > 0:
             t_u = st.cgupd_ms_total / st.cgupd_samples * 1e-3
-            roof["cg_update_kernel"] = {"avg_launch_us": round(t_u * 1e6, 2), "bytes_per_launch": 48 * n0,
-                                        "achieved": round(48 * n0 / t_u / 1e9, 1)}
+            # fused variant: x += alpha d and g += alpha h in one kernel (48 N); three-kernel variant: g only (24 N),
+            # x is brought up to date every 8 iterations by cg_xflush_kernel
+            upd_name, upd_bytes = ("cg_update_kernel", 48 * n0) if fused else ("cg_update_g_kernel", 24 * n0)
+            roof[upd_name] = {"avg_launch_us": round(t_u * 1e6, 2), "bytes_per_launch": upd_bytes,
+                              "achieved": round(upd_bytes / t_u / 1e9, 1)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

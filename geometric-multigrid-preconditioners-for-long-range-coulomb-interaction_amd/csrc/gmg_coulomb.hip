@@ -102,6 +102,8 @@ struct gmg_context {
   // coarse CG work space (level-0 sized)
   int64_t cg_n = 0;
   double *cg_g = nullptr, *cg_d0 = nullptr, *cg_d1 = nullptr, *cg_h = nullptr;
+  double *cg_ring[kXRing] = {};  // direction vectors of the last kXRing iterations (three-kernel coarse CG), allocated on first use
+  int64_t cg_ring_len = 0;
   CGState *st = nullptr;       // device
   CGState *st_host = nullptr;  // pinned, 2 slots (the chunk being checked / the speculative one)
   CGState st_final{};
@@ -1010,6 +1012,12 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
 }
 
 // frees every operator / work vector but keeps the stream, the reduction scratch and the communicator
+void free_cg_ring(gmg_context *ctx) {
+  for (double *&p : ctx->cg_ring)
+    if (p) { (void)hipFree(p); p = nullptr; }
+  ctx->cg_ring_len = 0;
+}
+
 void release_operators(gmg_context *ctx) {
   for (auto &L : ctx->lv) {
     free_csr(L.A); free_csr(L.I); free_csr(L.It); free_csr(L.P); free_csr(L.Pt);
@@ -1028,6 +1036,7 @@ void release_operators(gmg_context *ctx) {
   free_csr(ctx->S);
   for (double **p : {&ctx->sys_full_a, &ctx->sys_full_b, &ctx->S_invd, &ctx->S_tmp, &ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
+  free_cg_ring(ctx);
 }
 
 DevCSR *which_matrix(gmg_context *ctx, int which) {
@@ -1153,6 +1162,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     }
     ctx->cg_n = n_cols;
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
+    free_cg_ring(ctx);  // sized for the previous level 0
     ctx->stats.spmv0_rows = n_rows;
     ctx->stats.spmv0_nnz = rowptr[n_rows];
     ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) + (L.A.use_sellp ? 8 : 0) : 0;

@@ -67,6 +67,8 @@ __device__ __forceinline__ double reduce_partials(const double *p, int n, double
 
 // ---------------------------------------------------------------- coarse-CG device state
 
+constexpr int kXRing = 8;  // iterations whose x += alpha d is applied in one pass (cg_xflush_kernel)
+
 struct CGState {
   double gh[2];       // g.h of the previous / current iteration (slot = iteration parity)
   double res0;        // SolverControl::initial_value()
@@ -77,6 +79,7 @@ struct CGState {
   int status;         // 0 success, 1 no convergence (step >= max or NaN)
   int iters;          // SolverControl::last_step()
   int pad;
+  double alpha[kXRing];  // step lengths of the last kXRing iterations (slot = iteration % kXRing), three-kernel variant
 };
 
 // ---------------------------------------------------------------- CSR SpMV with LDS row window
@@ -616,7 +619,8 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
 // Distributed coarse CG: opens the iteration and forms d = beta d - g on the owned range;
 // the ghost entries of d arrive by halo exchange before the SpMV (CG = 2).
 struct CGDirArgs {
-  double *d;
+  double *d;            // out: direction of this iteration
+  const double *d_old;  // direction of the previous one (may alias d)
   const double *g;
   int64_t n;
   CGState *st;
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
   double beta = 0.0;
   if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kThreads)
-    a.d[i] = beta * a.d[i] - a.g[i];
+    a.d[i] = beta * a.d_old[i] - a.g[i];
 }
 
 // ---------------------------------------------------------------- coarse CG: init + update
@@ -707,6 +711,80 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(CGUpdateArgs a) {
   const double s = block_sum(acc, red);
   if (threadIdx.x == 0) a.part_gg[blockIdx.x] = s;
   if (blockIdx.x == 0 && threadIdx.x == 0) a.st->it_k2 = it + 1;
+}
+
+// Three-kernel variant: the update touches g only and leaves alpha in the state; x += alpha d is
+// applied for kXRing iterations at once by cg_xflush_kernel from a ring of direction vectors
+// (same additions in the same order: x is not read inside the iteration).
+struct CGUpdateGArgs {
+  double *g;
+  const double *h;
+  int64_t n;
+  CGState *st;
+  const double *part_dh;
+  int n_part_dh;
+  double *part_gg;
+};
+__global__ __launch_bounds__(kThreads) void cg_update_g_kernel(CGUpdateGArgs a) {
+  __shared__ double red[4];
+  if (a.st->done) return;
+  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
+  const int it = a.st->it_k1;
+  const double alpha = a.st->gh[it & 1] / dh;
+  double acc = 0.0;
+  const int64_t n2 = a.n >> 1;
+  const double2 *h2 = reinterpret_cast<const double2 *>(a.h);
+  double2 *g2 = reinterpret_cast<double2 *>(a.g);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
+    const double2 hv = h2[i];
+    double2 gv = g2[i];
+    gv.x += alpha * hv.x; gv.y += alpha * hv.y;
+    g2[i] = gv;
+    acc += gv.x * gv.x;
+    acc += gv.y * gv.y;
+  }
+  if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.n - 1;
+    const double gi = a.g[i] + alpha * a.h[i];
+    a.g[i] = gi;
+    acc += gi * gi;
+  }
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) a.part_gg[blockIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.st->alpha[it % kXRing] = alpha;
+    a.st->it_k2 = it + 1;
+  }
+}
+
+// x += sum_{i in [lo, min(completed iterations, upto))} alpha_i d_i, one iteration after the other per element
+struct CGXFlushArgs {
+  double *x;
+  const double *ring[kXRing];  // direction of iteration i lives in ring[i % kXRing]
+  int64_t n;
+  const CGState *st;
+  int lo, upto;
+};
+__global__ __launch_bounds__(kThreads) void cg_xflush_kernel(CGXFlushArgs a) {
+  const int hi = min(a.st->it_k2, a.upto);  // it_k2 does not change while this kernel runs (stream order)
+  if (hi <= a.lo) return;
+  const int64_t n2 = a.n >> 1;
+  double2 *x2 = reinterpret_cast<double2 *>(a.x);
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n2; e += (int64_t)gridDim.x * kThreads) {
+    double2 xv = x2[e];
+    for (int i = a.lo; i < hi; ++i) {
+      const double alpha = a.st->alpha[i % kXRing];
+      const double2 dv = reinterpret_cast<const double2 *>(a.ring[i % kXRing])[e];
+      xv.x += alpha * dv.x; xv.y += alpha * dv.y;
+    }
+    x2[e] = xv;
+  }
+  if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t e = a.n - 1;
+    double xv = a.x[e];
+    for (int i = a.lo; i < hi; ++i) xv += a.st->alpha[i % kXRing] * a.ring[i % kXRing][e];
+    a.x[e] = xv;
+  }
 }
 
 // ---------------------------------------------------------------- BLAS-1 / gather / scatter

@@ -23,9 +23,15 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
   const int g_vec = grid_for(n);
   const int g_upd = grid_for(n / 2);
   double *s_gg = ctx->scal_dev + 4, *s_dh = ctx->scal_dev + 5;
-  double *d = ctx->cg_d0;
+  // ring of direction vectors (with ghost tails): x += alpha d is applied kXRing iterations at a time
+  if (!ctx->cg_ring[0]) {
+    for (int r = 0; r < kXRing; ++r) CHK(alloc_vec(ctx, &ctx->cg_ring[r], A.n_cols));
+    ctx->cg_ring_len = A.n_cols;
+  }
+  if (ctx->cg_ring_len < A.n_cols) return fail(ctx, GMG_ERR_INVALID, "coarse CG ring sized for a smaller operator");
 
-  CGInitArgs ia{b, x, ctx->cg_g, ctx->cg_d0, ctx->cg_d1, n, ctx->st, ctx->part_b};
+  // the direction read by iteration 0 (beta = 0) must be finite: the init kernel zeroes it
+  CGInitArgs ia{b, x, ctx->cg_g, ctx->cg_ring[kXRing - 1], ctx->cg_ring[kXRing - 1], n, ctx->st, ctx->part_b};
   hipLaunchKernelGGL(cg_init_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, ia);
   // where the consumers find the reduced scalars: all-reduced single values, or the raw partials
   const double *gg_src = ctx->part_b;
@@ -38,8 +44,17 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
 
   const int maxit = ctx->coarse_maxit;
   ctx->ev_used = 0; ctx->ev2_used = 0;
+  auto flush_x = [&](int lo, int upto) {
+    CGXFlushArgs fa{};
+    fa.x = x; fa.n = n; fa.st = ctx->st; fa.lo = lo; fa.upto = upto;
+    for (int r = 0; r < kXRing; ++r) fa.ring[r] = ctx->cg_ring[r];
+    hipLaunchKernelGGL(cg_xflush_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, fa);
+  };
+  int launched_total = 0;
   CHK(run_cg_chunks(ctx, (!ctx->dist && L0.n >= kUnfusedMinRows) ? 3 : 6, [&](int launched) -> int {
-    CGDirArgs da{d, ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
+    launched_total = launched + 1;
+    double *d = ctx->cg_ring[launched % kXRing];
+    CGDirArgs da{d, ctx->cg_ring[(launched + kXRing - 1) % kXRing], ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};
     hipLaunchKernelGGL(cg_direction_kernel, dim3(g_vec), dim3(kThreads), 0, ctx->stream, da);
     if (comm && halo_exchange(ctx->comm, A.halo, d, n, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
     SpmvArgs a = base_args(A, d, ctx->cg_h);
@@ -56,11 +71,12 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
       if (allreduce_sum(ctx->comm, s_dh, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
       dh_src = s_dh; dh_n = 1;
     }
-    CGUpdateArgs ua{x, ctx->cg_g, d, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
+    CGUpdateGArgs ua{ctx->cg_g, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
     const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
     if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
+    hipLaunchKernelGGL(cg_update_g_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
     if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+    if ((launched + 1) % kXRing == 0) flush_x(launched + 1 - kXRing, launched + 1);
     if (comm) {
       hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);
       if (allreduce_sum(ctx->comm, s_gg, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
@@ -69,6 +85,8 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
     }
     return GMG_OK;
   }));
+  // iterations not covered by an enqueued pass: [kXRing * floor(launched / kXRing), completed)
+  flush_x(launched_total / kXRing * kXRing, INT_MAX);
   collect_profile_samples(ctx);
   ctx->last_coarse_iters = ctx->st_final.iters;
   ctx->stats.coarse_solves++;
