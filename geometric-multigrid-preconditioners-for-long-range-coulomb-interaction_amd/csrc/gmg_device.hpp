@@ -492,9 +492,6 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
   const SellArgs &sa = pa.sa;
   const SpmvArgs &a = sa.a;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if constexpr (CG == 2) {
-    if (a.st->done) return;
-  }
   // consecutive workgroups go to consecutive XCDs: wave index = (xcd, workgroup within the xcd, wave), so
   // that every XCD (own L2) walks one contiguous range of slices
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
@@ -508,7 +505,11 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
     m_qe = sa.qptr[s0 + lane + 1];
     m_pid = sa.spat[s0 + lane];
   }
-  dict[threadIdx.x] = sa.dict[threadIdx.x];
+  const double dict_mine = sa.dict[threadIdx.x];
+  if constexpr (CG == 2) {
+    if (a.st->done) return;  // read after the loads above were issued: one round trip for all three
+  }
+  dict[threadIdx.x] = dict_mine;
   __syncthreads();
   double dot_acc = 0.0;
   const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
@@ -631,10 +632,27 @@ struct CGDirArgs {
 };
 __global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
   __shared__ double red[4];
+  if (a.st->done) return;
+  const int64_t n2 = a.n >> 1;
+  const double2 *o2 = reinterpret_cast<const double2 *>(a.d_old);
+  const double2 *g2 = reinterpret_cast<const double2 *>(a.g);
+  double2 *d2 = reinterpret_cast<double2 *>(a.d);
+  // the first pair of every thread is on its way while the partials are reduced and the iteration is opened
+  const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  double2 ov{0.0, 0.0}, gv{0.0, 0.0};
+  if (i0 < n2) { ov = o2[i0]; gv = g2[i0]; }
   double beta = 0.0;
   if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kThreads)
+  for (int64_t i = i0; i < n2; i += stride) {
+    if (i != i0) { ov = o2[i]; gv = g2[i]; }
+    double2 dv;
+    dv.x = beta * ov.x - gv.x; dv.y = beta * ov.y - gv.y;
+    d2[i] = dv;
+  }
+  if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = a.n - 1;
     a.d[i] = beta * a.d_old[i] - a.g[i];
+  }
 }
 
 // ---------------------------------------------------------------- coarse CG: init + update
@@ -683,18 +701,21 @@ struct CGUpdateArgs {
 __global__ __launch_bounds__(kThreads) void cg_update_kernel(CGUpdateArgs a) {
   __shared__ double red[4];
   if (a.st->done) return;
-  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
-  const int it = a.st->it_k1;
-  const double alpha = a.st->gh[it & 1] / dh;
-  double acc = 0.0;
   const int64_t n2 = a.n >> 1;
   const double2 *d2 = reinterpret_cast<const double2 *>(a.d);
   const double2 *h2 = reinterpret_cast<const double2 *>(a.h);
   double2 *x2 = reinterpret_cast<double2 *>(a.x);
   double2 *g2 = reinterpret_cast<double2 *>(a.g);
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
-    const double2 dv = d2[i], hv = h2[i];
-    double2 xv = x2[i], gv = g2[i];
+  // the first pairs of every thread are on their way while the partials are reduced
+  const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  double2 dv{0.0, 0.0}, hv{0.0, 0.0}, xv{0.0, 0.0}, gv{0.0, 0.0};
+  if (i0 < n2) { dv = d2[i0]; hv = h2[i0]; xv = x2[i0]; gv = g2[i0]; }
+  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
+  const int it = a.st->it_k1;
+  const double alpha = a.st->gh[it & 1] / dh;
+  double acc = 0.0;
+  for (int64_t i = i0; i < n2; i += stride) {
+    if (i != i0) { dv = d2[i]; hv = h2[i]; xv = x2[i]; gv = g2[i]; }
     xv.x += alpha * dv.x; xv.y += alpha * dv.y;
     gv.x += alpha * hv.x; gv.y += alpha * hv.y;
     x2[i] = xv; g2[i] = gv;
@@ -728,16 +749,19 @@ struct CGUpdateGArgs {
 __global__ __launch_bounds__(kThreads) void cg_update_g_kernel(CGUpdateGArgs a) {
   __shared__ double red[4];
   if (a.st->done) return;
+  const int64_t n2 = a.n >> 1;
+  const double2 *h2 = reinterpret_cast<const double2 *>(a.h);
+  double2 *g2 = reinterpret_cast<double2 *>(a.g);
+  // the first pair of every thread (most of the vector at this grid) is on its way while the partials are reduced
+  const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
+  double2 hv{0.0, 0.0}, gv{0.0, 0.0};
+  if (i0 < n2) { hv = h2[i0]; gv = g2[i0]; }
   const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
   const int it = a.st->it_k1;
   const double alpha = a.st->gh[it & 1] / dh;
   double acc = 0.0;
-  const int64_t n2 = a.n >> 1;
-  const double2 *h2 = reinterpret_cast<const double2 *>(a.h);
-  double2 *g2 = reinterpret_cast<double2 *>(a.g);
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) {
-    const double2 hv = h2[i];
-    double2 gv = g2[i];
+  for (int64_t i = i0; i < n2; i += stride) {
+    if (i != i0) { hv = h2[i]; gv = g2[i]; }
     gv.x += alpha * hv.x; gv.y += alpha * hv.y;
     g2[i] = gv;
     acc += gv.x * gv.x;

@@ -21,4 +21,7 @@ cd $R
 bash tools/gpu_pmc_traffic.sh atoms64000 > $O/pmc_traffic.log 2>&1 || { tail -5 $O/pmc_traffic.log; exit 4; }
 cp $R/gpurun_out/pmc_traffic_atoms64000.json $O/
 rm -rf $R/gpurun_out/pmc_traffic
-tail -3 $O/bench_default.json | cut -c1-600
+# the driver's launch line for N = 1 (one-process-per-GPU layout, RCCL communicator of one rank)
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err || { tail -5 $O/bench_torchrun1.err; exit 5; }
+python tools/print_bench.py $O/bench_torchrun1.json
+python tools/print_bench.py $O/bench_default.json
