@@ -774,6 +774,10 @@ int allgather_full(gmg_context *ctx, double *full, const double *local, int64_t 
   part_range(n_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
   // stage the owned slice at its place; the padded tail of the last chunks is never read
   if (e > b) HIPC(hipMemcpyAsync(full + b, local, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ctx->comm.shm) {
+    if (shm_allgather(ctx->comm, full, c, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-gather (shared memory) failed");
+    return GMG_OK;
+  }
   if (ncclAllGather(full + (int64_t)ctx->comm.rank * c, full, (size_t)c, ncclDouble, ctx->comm.comm, ctx->stream) != ncclSuccess)
     return fail(ctx, GMG_ERR_COMM, "all-gather failed");
   return GMG_OK;

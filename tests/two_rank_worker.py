@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""One rank of tests/test_gpu_two_ranks.py: the six adaptive cycles of the reference's regression
+test with the solve on the GPU in the one-process-per-GPU layout (partitioned system matrix and
+level 0, halo exchange, all-reduces, all-gathers), on the communicator named by the id.
+
+usage: two_rank_worker.py RANK N_RANKS ID_HEX GOLDEN_DIR OUT_JSON [nacl]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root: the package and oracle/
+from gpu_util import pkg  # noqa: E402
+
+
+def main():
+    rank, n_ranks, uid = int(sys.argv[1]), int(sys.argv[2]), bytes.fromhex(sys.argv[3])
+    golden_dir, out = sys.argv[4], sys.argv[5]
+    nacl = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    S = pkg().step50
+    if nacl:  # lattice of nacl^3 atoms, Jacobi smoother: the bench's kind of problem, three-kernel coarse CG on request
+        cycles = 2
+        p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
+                                 bc="Homogeneous", cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1,
+                                 global_refinement=0, smoother="Jacobi"))
+        p.set_nacl_atoms(nacl)
+    else:
+        cycles = 6
+        p = S.Problem(S.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
+                                 cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0,
+                                 smoother="SSOR"))
+        p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
+    if n_ranks > 0:
+        p.set_communicator(rank, n_ranks, uid)
+    reps = [dict(p.run_cycle(c, on_device=True)) for c in range(cycles)]
+    with open(out, "w") as fh:
+        json.dump(reps, fh)
+
+
+if __name__ == "__main__":
+    main()
