@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--workload", default="atoms64000", choices=sorted(WORKLOADS))
     ap.add_argument("--smoother", default="Jacobi", choices=["Jacobi", "SSOR", "Chebyshev"])
     ap.add_argument("--cycles", type=int, default=5, help="adaptive cycles to run (the reference runs 5); the last one is timed")
+    ap.add_argument("--partition-level0", default="auto", choices=["auto", "always", "never"],
+                    help="N > 1: row-partition level 0 (coarse CG over RCCL) or keep it replicated; auto decides by size (DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8)
     args = ap.parse_args()
@@ -91,7 +93,7 @@ def main():
     S.set_threads(max(1, min(16, (os.cpu_count() or 16) // max(1, world))))
     p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
-                             quad_rhs=1, global_refinement=0, smoother=args.smoother))
+                             quad_rhs=1, global_refinement=0, smoother=args.smoother, partition_level0=args.partition_level0))
     p.set_nacl_atoms(w["nacl"])
     if launched:
         # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
@@ -187,7 +189,10 @@ def main():
                        "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
                        "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
                        "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),
-                       "parallelism": f"{world} rank(s), one per GPU"},
+                       "parallelism": f"{world} rank(s), one per GPU" + ("" if world == 1 else (
+                           "; system matrix + outer CG rows partitioned, level 0 " +
+                           ("partitioned (halo exchange + 2 all-reduces per coarse iteration over RCCL)" if int(n0) < rep["dofs_by_level"][0]
+                            else "replicated (too small to pay three collectives per coarse iteration), levels >= 1 replicated")))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

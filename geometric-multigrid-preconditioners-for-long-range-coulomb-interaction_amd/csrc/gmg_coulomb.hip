@@ -123,7 +123,7 @@ struct gmg_context {
   gmg_stats stats{};
   Comm comm;
   bool dist = false;             // communicator initialised: level 0 + system rows are partitioned
-  int64_t sys_global = 0, l0_global = 0;
+  int64_t sys_global = 0, l0_global = 0;  // l0_global == 0 on a communicator: level 0 is replicated, only the outer CG is partitioned
   double *sys_full_a = nullptr, *sys_full_b = nullptr;  // replicated src / dst of the V-cycle
   std::string err;
 };
@@ -161,6 +161,9 @@ inline hipError_t stream_wait(hipStream_t s) {
 }
 
 constexpr int64_t kTileMaxRowsEarly = 1024;
+
+// level 0 (matrix, coarse CG vectors) is row-partitioned over the ranks
+inline bool l0_partitioned(const gmg_context *ctx) { return ctx->dist && ctx->l0_global > 0; }
 
 inline int grid_for(int64_t n) {
   int64_t g = (n + kThreads - 1) / kThreads;
@@ -685,7 +688,7 @@ int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
   };
   int slot = 0;
   CHK(launch_chunk(std::min(first, maxit + 1), slot));
-  const bool speculate = !ctx->dist;  // no-op iterations still exchange halos / all-reduce: not worth it across ranks
+  const bool speculate = !l0_partitioned(ctx);  // no-op iterations still exchange halos / all-reduce: not worth it across ranks
   for (;;) {
     if (speculate) CHK(launch_chunk(later, slot ^ 1));
     for (;;) {
@@ -712,7 +715,7 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   if (!A.valid) return fail(ctx, GMG_ERR_INVALID, "level-0 matrix not set");
   int variant = ctx->cg_variant;
   if (const char *ev = std::getenv("GMG_CG_VARIANT")) variant = std::atoi(ev);  // tuning experiments
-  if (ctx->dist || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2)
+  if (l0_partitioned(ctx) || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2)
   {
     ctx->stats.coarse_variant = 2;
     return coarse_solve_unfused(ctx, x, b, iters_out, res_out);
@@ -786,7 +789,7 @@ int allgather_full(gmg_context *ctx, double *full, const double *local, int64_t 
 // MGCoarseGridBase::operator() as the V-cycle sees it: replicated defect in, replicated solution out
 int coarse_level_solve(gmg_context *ctx) {
   Level &L0 = ctx->lv[0];
-  if (!ctx->dist) return coarse_solve(ctx, L0.sol, L0.def, nullptr, nullptr);
+  if (!l0_partitioned(ctx)) return coarse_solve(ctx, L0.sol, L0.def, nullptr, nullptr);
   int64_t b, e;
   part_range(ctx->l0_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
   if (e > b) HIPC(hipMemcpyAsync(L0.def, L0.def_full + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
@@ -836,7 +839,7 @@ int vcycle(gmg_context *ctx, double *dst, const double *src) {
     Level &L = ctx->lv[(size_t)l];
     if (!L.A.valid) return fail(ctx, GMG_ERR_INVALID, "level matrix not set");
     double *def = (l == 0) ? L.def_full : L.def;
-    const int64_t nl = (l == 0 && ctx->dist) ? ctx->l0_global : L.n_vec;
+    const int64_t nl = (l == 0 && l0_partitioned(ctx)) ? ctx->l0_global : L.n_vec;
     HIPC(hipMemsetAsync(def, 0, sizeof(double) * (size_t)nl, ctx->stream));
     if (l > 0) HIPC(hipMemsetAsync(L.sol, 0, sizeof(double) * (size_t)L.n_vec, ctx->stream));
     if (L.n_copy)
@@ -1153,7 +1156,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
   for (double **p : {&L.sol, &L.def, &L.t, &L.w1, &L.w2, &L.w3}) CHK(alloc_vec(ctx, p, n_cols));
   if (level > 0) CHK(setup_sgs(ctx, L, n_rows, rowptr, col, val));
   if (level == 0) {
-    if (ctx->dist) {
+    if (l0_partitioned(ctx)) {
       const int64_t padded = part_chunk(ctx->l0_global, ctx->comm.n_ranks) * ctx->comm.n_ranks;
       if (L.sol_full && L.sol_full != L.sol) (void)hipFree(L.sol_full);
       if (L.def_full && L.def_full != L.def) (void)hipFree(L.def_full);

@@ -18,7 +18,7 @@ constexpr int64_t kUnfusedMinRows = 400000;
 int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out) {
   Level &L0 = ctx->lv[0];
   DevCSR &A = L0.A;
-  const bool comm = ctx->dist;
+  const bool comm = l0_partitioned(ctx);
   const int64_t n = L0.n;
   const int g_vec = grid_for(n);
   const int g_upd = grid_for(n / 2);
@@ -51,7 +51,7 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
     hipLaunchKernelGGL(cg_xflush_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, fa);
   };
   int launched_total = 0;
-  CHK(run_cg_chunks(ctx, (!ctx->dist && L0.n >= kUnfusedMinRows) ? 3 : 6, [&](int launched) -> int {
+  CHK(run_cg_chunks(ctx, (!comm && L0.n >= kUnfusedMinRows) ? 3 : 6, [&](int launched) -> int {
     launched_total = launched + 1;
     double *d = ctx->cg_ring[launched % kXRing];
     CGDirArgs da{d, ctx->cg_ring[(launched + kXRing - 1) % kXRing], ctx->cg_g, n, ctx->st, gg_src, gg_n, ctx->coarse_tol, maxit};

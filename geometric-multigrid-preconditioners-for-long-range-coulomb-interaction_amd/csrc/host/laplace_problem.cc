@@ -202,7 +202,8 @@ void ParameterReader::declare_parameters() {
             {"Polynomial degree", "1"}, {"Preconditioner", "GMG"}, {"Lammps input file", "atom_8.data"},
             // additions of this build (the reference selects the smoother by editing :969-970)
             {"Smoother", "SSOR"}, {"Smoother damping", "0.5"}, {"Smoother steps", "2"}, {"Chebyshev degree", "2"},
-            {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}, {"Charge densities on device", "true"}};
+            {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}, {"Charge densities on device", "true"},
+            {"Partition level 0", "auto"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -264,6 +265,7 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.device_resident_outer_cg = prm.get_bool("Device resident outer CG");
   p.ssor_blocks = (int)prm.get_integer("SSOR blocks");
   p.densities_on_device = prm.get_bool("Charge densities on device");
+  p.partition_level0 = prm.get("Partition level 0");
   return p;
 }
 
@@ -1010,8 +1012,13 @@ int LaplaceProblem<dim>::upload() {
   const CSRMatrix &S = system_matrix;
   if (distributed) {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),
-    // levels >= 1, transfers and copy indices are replicated
-    GMGC(gmg_set_global_sizes(gmg, S.n_rows, mg_matrices[0].n_rows));
+    // levels >= 1, transfers and copy indices are replicated.  A level 0 whose
+    // coarse-CG iteration is shorter than the three collectives it would need stays replicated.
+    const int64_t n0 = mg_matrices[0].n_rows;
+    // rows taken off every rank's coarse iteration (28 ps per row on one MI355X) against ~3 x 15 us of collectives
+    level0_partitioned = par.partition_level0 == "always" ||
+                         (par.partition_level0 != "never" && n0 - n0 / n_ranks >= kPartitionMinRowsSaved);
+    GMGC(gmg_set_global_sizes(gmg, S.n_rows, level0_partitioned ? n0 : 0));
     const LocalOperator Sl = localize(S, rank, n_ranks);
     GMGC(gmg_set_system_matrix(gmg, Sl.A.n_rows, Sl.A.n_cols, Sl.A.rowptr.data(), Sl.A.col.data(), Sl.A.val.data()));
     GMGC(gmg_set_halo_plan(gmg, GMG_SYSTEM, (int)Sl.halo.neighbor_rank.size(), Sl.halo.neighbor_rank.data(),
@@ -1023,7 +1030,7 @@ int LaplaceProblem<dim>::upload() {
   }
   for (int l = 0; l < L; ++l) {
     const CSRMatrix &A = mg_matrices[(size_t)l];
-    if (distributed && l == 0) {
+    if (distributed && level0_partitioned && l == 0) {
       const LocalOperator Al = localize(A, rank, n_ranks);
       GMGC(gmg_set_level_matrix(gmg, 0, Al.A.n_rows, Al.A.n_cols, Al.A.rowptr.data(), Al.A.col.data(), Al.A.val.data()));
       GMGC(gmg_set_halo_plan(gmg, 0, (int)Al.halo.neighbor_rank.size(), Al.halo.neighbor_rank.data(), Al.halo.send_count.data(),

@@ -63,6 +63,7 @@ struct Parameters {
   bool densities_on_device = true;  // compute_charge_densities() through gmg_charge_density when a device is in use
   int ssor_blocks = 1;  // 1: exact sequential SGS (mpirun=1); B: rank-local SGS on B blocks (mpirun=B)
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
+  std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
   static Parameters from(const ParameterReader &prm);
 };
 
@@ -133,6 +134,8 @@ class LaplaceProblem {
   // setup is replicated, the operators are cut by partition.h at upload()
   int rank = 0, n_ranks = 1;
   bool distributed = false;
+  bool level0_partitioned = false;  // decided per cycle in upload() ("Partition level 0")
+  static constexpr int64_t kPartitionMinRowsSaved = 2500000;
   std::string comm_id;  // gmg_comm_unique_id of rank 0, broadcast by the launcher
   void set_communicator(int rank_, int n_ranks_, const std::string &id) { rank = rank_; n_ranks = n_ranks_; comm_id = id; distributed = true; }
 

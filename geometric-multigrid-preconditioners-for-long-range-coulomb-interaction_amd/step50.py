@@ -75,6 +75,7 @@ def prm_text(**kw) -> str:
         "device_cg": ("Solver input data", "Device resident outer CG"),
         "ssor_blocks": ("Solver input data", "SSOR blocks"),
         "densities_on_device": ("Misc", "Charge densities on device"),
+        "partition_level0": ("Solver input data", "Partition level 0"),
     }
     sections = {}
     for k, v in kw.items():

@@ -149,6 +149,8 @@ int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
  * coarse CG) are row-partitioned in equal chunks -- gmg_partition_range gives the canonical
  * owned range, mirroring locally_owned_dofs() of the reference (:656-657) -- while levels >= 1,
  * the transfers and the copy-index lists are passed whole (global numbering) on every rank.
+ * n_level0_global = 0 keeps level 0 replicated as well (matrix passed whole, every rank runs
+ * the single-GPU coarse CG): for a level 0 too small to pay three collectives per iteration.
  * Call order: gmg_comm_init, gmg_set_global_sizes, then the gmg_set_* of the operators.   */
 int gmg_set_global_sizes(gmg_context *ctx, int64_t n_system_global, int64_t n_level0_global);
 int gmg_partition_range(int64_t n_global, int rank, int n_ranks, int64_t *begin, int64_t *end);

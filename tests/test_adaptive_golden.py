@@ -24,7 +24,7 @@ def run_cycles(golden_dir, n_cycles, solve, communicator=False):
     pkg().build.build_all()
     p = S.Problem(S.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
                              cycles=n_cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0,
-                             smoother="SSOR"))
+                             smoother="SSOR", partition_level0="always"))
     p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
     if communicator:  # the N > 1 layout on a 1-rank RCCL communicator, kept across cycles (gmg_reset)
         p.set_communicator(0, 1, pkg().capi.Context.unique_id())

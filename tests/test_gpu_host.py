@@ -66,14 +66,16 @@ def test_distributed_layout_on_one_rank(golden):
     upper levels, all-gathers around the V-cycle) with world size 1 must reproduce the golden."""
     g = golden["tests_3D/step-16.mpirun=1"]["runs"][0]["cycles"][0]
     capi = pkg().capi
-    p = _problem(left=0, right=1, problem="Step16", dim=3, bc="Homogeneous", cycles=1, global_refinement=4, smoother="Jacobi")
+    p = _problem(left=0, right=1, problem="Step16", dim=3, bc="Homogeneous", cycles=1, global_refinement=4, smoother="Jacobi",
+                 partition_level0="always")
     p.set_communicator(0, 1, capi.Context.unique_id())
     r = p.run_cycle(0)
     assert r["cg_iterations"] == g["cg_iterations"] == 8
     for k in ("sol_l1", "sol_l2", "sol_linf"):
         assert rel_close(r[k], g[k], 6)
     p2 = _problem(left=0, right=1, mesh_size=0.25, vacuum=4, problem="GaussianCharges", dim=3, bc="Inhomogeneous", cycles=1,
-                  r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi")
+                  r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi",
+                  partition_level0="always")
     p2.set_nacl_atoms(1)
     ref = _problem(left=0, right=1, mesh_size=0.25, vacuum=4, problem="GaussianCharges", dim=3, bc="Inhomogeneous", cycles=1,
                    r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi")

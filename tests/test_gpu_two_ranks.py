@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None):
+def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None, part="always"):
     """n_ranks = 0: one plain process without a communicator (the single-GPU layout)"""
     monkeypatch.setenv("GMG_COMM_TRANSPORT", "shm")
     monkeypatch.setenv("GMG_SHM_SLOT_MB", "8")
@@ -31,9 +31,9 @@ def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None
     name = uid[len(b"GMGSHM:"):].split(b"\0")[0].decode()
     env = dict(os.environ)
     env.update(env_extra or {})
-    outs = [str(tmp_path / f"n{n_ranks}_rank{r}.json") for r in range(max(1, n_ranks))]
+    outs = [str(tmp_path / f"n{n_ranks}_{part}_rank{r}.json") for r in range(max(1, n_ranks))]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(n_ranks), uid.hex(), golden_dir,
-                               outs[r]] + ([str(nacl)] if nacl else []), env=env) for r in range(max(1, n_ranks))]
+                               outs[r]] + ([str(nacl), part] if nacl else []), env=env) for r in range(max(1, n_ranks))]
     try:
         for p in procs:
             assert p.wait(timeout=280) == 0
@@ -70,6 +70,9 @@ def test_three_kernel_coarse_cg_on_two_ranks(golden_dir, tmp_path, monkeypatch):
     all-reduced dot products), two adaptive cycles."""
     two = run_ranks(2, golden_dir, tmp_path, monkeypatch, nacl=1)
     one = run_ranks(0, golden_dir, tmp_path, monkeypatch, nacl=1)[0]
+    # "Partition level 0 = auto": a 45^3 level 0 stays replicated (every rank runs the single-GPU coarse CG),
+    # the system matrix and the outer CG vectors are still partitioned
+    two += run_ranks(2, golden_dir, tmp_path, monkeypatch, nacl=1, part="auto")
     for reps in two:
         for r, g in zip(reps, one):
             assert r["dofs_by_level"] == g["dofs_by_level"] and r["cg_iterations"] == g["cg_iterations"]
