@@ -394,8 +394,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
           for (size_t u = 0; u < 9; ++u) m.sellp_centre[u] = dl[3 * u + 1];
         }
         const char *no_p = std::getenv("GMG_DISABLE_SELLP");
-        // worth it when (nearly) the whole operator is patterned: the streamed slices of this kernel are not pipelined
-        m.use_sellp = val8 && !(no_p && no_p[0] == '1') && n_run_slices * 10 >= n_slices * 9;
+        // a streamed slice costs ~4 pattern slices here against ~2.2 in the per-entry kernel: worth it up to ~40 % streamed slices
+        m.use_sellp = val8 && !(no_p && no_p[0] == '1') && n_run_slices * 10 >= n_slices * 7;
       }
       m.sell = true;
       m.n_slices = (int)n_slices;
@@ -477,7 +477,7 @@ template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
     SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
-    if constexpr (CG != 1) if (m.use_sellp) {
+    if (m.use_sellp) {
       SellPatArgs pa{};
       pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
       for (int u = 0; u < 9; ++u) pa.centre[u] = m.sellp_centre[u];
@@ -661,7 +661,7 @@ void collect_profile_samples(gmg_context *ctx) {
   }
 }
 
-constexpr int64_t kUnfusedMinRowsDecl = 400000;
+constexpr int64_t kUnfusedMinRowsDecl = 200000;
 
 // Enqueues coarse-CG iterations in chunks and watches the 64-byte device state.  The first
 // chunk is sized from the previous solve (zero-start solves of one hierarchy need nearly the

@@ -485,8 +485,8 @@ __device__ __forceinline__ double lane_double(double v, int l) {  // l: wave-uni
 constexpr int kSellpWaves = 6;  // resident waves per SIMD (= workgroups per CU) the register budget of the kernel is set for
 
 template <int MODE, int CG>
-__global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellPatArgs pa) {
-  static_assert(CG != 1, "the pattern kernel serves the plain and the unfused-CG products");
+__global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_sellp_kernel(SellPatArgs pa) {
+  constexpr bool XFORM = (CG == 1);  // fused opener: the operand is beta d_old - g, formed on the fly (small level 0)
   __shared__ double red[4];
   __shared__ double dict[256];
   const SellArgs &sa = pa.sa;
@@ -506,18 +506,27 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
     m_pid = sa.spat[s0 + lane];
   }
   const double dict_mine = sa.dict[threadIdx.x];
+  double beta = 0.0;
+  if constexpr (CG == 1) {
+    if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
+  }
   if constexpr (CG == 2) {
     if (a.st->done) return;  // read after the loads above were issued: one round trip for all three
   }
   dict[threadIdx.x] = dict_mine;
   __syncthreads();
+  auto X = [&](size_t c) -> double {
+    if constexpr (XFORM) return beta * a.x[c] - a.g[c];
+    else return a.x[c];
+  };
   double dot_acc = 0.0;
   const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
-  const double *xb[9];
+  const double *xb[9], *gb[9];
   int my_centre = pa.centre[0];  // lanes 0..8 <-> runs (lanes >= 9 repeat run 0: harmless, in range)
 #pragma unroll
   for (int u = 0; u < 9; ++u) {
     xb[u] = a.x + pa.centre[u];
+    gb[u] = XFORM ? a.g + pa.centre[u] : nullptr;
     if (lane == u) my_centre = pa.centre[u];
   }
 
@@ -538,10 +547,18 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
       uchar4 k[7];
 #pragma unroll
       for (int u = 0; u < 9; ++u) p[u] = *reinterpret_cast<const double2 *>(xb[u] + row);  // 8-byte aligned 16-byte load
+      if constexpr (XFORM) {
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          const double2 gv = *reinterpret_cast<const double2 *>(gb[u] + row);
+          p[u].x = beta * p[u].x - gv.x;
+          p[u].y = beta * p[u].y - gv.y;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 7; ++u) k[u] = kbase[(size_t)(qb + u) * 64];
       if (!have_carry) {  // first slice of the wave (or after a streamed slice): lane u fetches the element left of run u
-        const double e = a.x[(size_t)s * 64 - 1 + my_centre];
+        const double e = X((size_t)s * 64 - 1 + my_centre);
 #pragma unroll
         for (int u = 0; u < 9; ++u) carry[u] = lane_double(e, u);
       }
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
       uchar4 kq{0, 0, 0, 0};
       if (qb < qe) { kq = kbase[(size_t)qb * 64]; cols_of(qb, c); }
       for (int q = qb; q < qe; ++q) {
-        const double v0 = a.x[c[0]], v1 = a.x[c[1]], v2 = a.x[c[2]], v3 = a.x[c[3]];
+        const double v0 = X((size_t)c[0]), v1 = X((size_t)c[1]), v2 = X((size_t)c[2]), v3 = X((size_t)c[3]);
         const uchar4 k0 = kq;
         if (q + 1 < qe) { kq = kbase[(size_t)(q + 1) * 64]; cols_of(q + 1, c); }
         acc += dict[k0.x] * v0; acc += dict[k0.y] * v1; acc += dict[k0.z] * v2; acc += dict[k0.w] * v3;
@@ -598,8 +615,9 @@ __global__ __launch_bounds__(kThreads, kSellpWaves) void spmv_sellp_kernel(SellP
     }
     if (valid) {
       const int r = row;
-      if constexpr (CG == 2) {
-        if (!have_self) self = a.x[r];
+      if constexpr (CG != 0) {
+        if (!have_self) self = X((size_t)r);
+        if constexpr (XFORM) a.dnew[r] = self;
         a.y[r] = acc; dot_acc += self * acc;
       } else if constexpr (MODE == kStore) a.y[r] = acc;
       else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;

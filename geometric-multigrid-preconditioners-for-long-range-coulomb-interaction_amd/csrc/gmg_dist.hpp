@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int64_t kUnfusedMinRows = 400000;
+constexpr int64_t kUnfusedMinRows = 200000;
 
 int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iters_out, double *res_out) {
   Level &L0 = ctx->lv[0];
