@@ -146,8 +146,8 @@ def main():
         val8, col16 = bool(lay >= 1 and (lay - 1) & 2), bool(lay >= 1 and (lay - 1) & 4)
         tmpl = f"0, {1 if fused else 2}" + (f", {'true' if val8 else 'false'}, {'true' if col16 else 'false'}" if lay >= 1 else "")
         kname = ("spmv_sell_kernel" if lay >= 1 else "spmv_tile_kernel") + f"<{tmpl}>"
-        if lay >= 1 and (lay - 1) & 8 and not fused:  # lattice operator: pattern-run kernel (pair loads + lane shift)
-            kname = "spmv_sellp_kernel<0, 2>"
+        if lay >= 1 and (lay - 1) & 8:  # lattice operator: pattern-run kernel (pair loads + lane shift)
+            kname = f"spmv_sellp_kernel<0, {1 if fused else 2}>"
         # bytes the internal layout actually streams: SELL-64 pads rows to a multiple of 4 entries;
         # values are 1-byte dictionary codes (val8) or fp64, columns 2-byte offsets (col16) or int32
         # (pattern slices stream no columns at all); the library reports the exact size of those streams
