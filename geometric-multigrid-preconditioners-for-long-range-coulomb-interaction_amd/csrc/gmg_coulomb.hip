@@ -674,7 +674,7 @@ template <class EnqueueOne>
 int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
   const int maxit = ctx->coarse_maxit;
   const int last = ctx->last_coarse_iters;
-  const int first = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (last > 8 ? last - (later_default < 6 ? std::max(2, last / 8) : 2) : 16);
+  const int first = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : (last > 8 ? last - (later_default < 6 ? std::max(2, last / 4) : 2) : 16);
   const int later = ctx->coarse_chunk > 0 ? ctx->coarse_chunk : later_default;
   int launched = 0;
   auto launch_chunk = [&](int n, int slot) -> int {
