@@ -65,6 +65,36 @@ def test_sell_variants_bit_exact(case, expect, monkeypatch):
     assert np.array_equal(y, go.spmv(m, x))
 
 
+@pytest.mark.parametrize("kind,name", [(0, "jacobi"), (2, "chebyshev")])
+@pytest.mark.parametrize("from_zero", [True, False])
+def test_smoother_epilogues_on_the_pattern_run_kernel(kind, name, from_zero):
+    """Damped-Jacobi and Chebyshev steps are epilogues of the SpMV kernels: here on an operator that
+    is served by the pattern-run kernel (27 consecutive columns, 5 distinct values), as level 1 of a
+    synthetic two-level hierarchy, bit for bit against the oracle's smoother."""
+    rng = np.random.default_rng(21)
+    n = 64 * 40 + 17
+    A1 = banded(n, 27, rng, np.array([-1 / 6, -1 / 12, 8 / 3, 0.0, 1.25]), 1)
+    A0 = banded(64, 3, rng)
+    P = csr(n, 64, [([i % 64], [1.0]) for i in range(n)])
+    empty = SimpleNamespace(n_rows=0, n_cols=0, rowptr=np.zeros(1, dtype=np.int64), col=np.zeros(0, dtype=np.int32),
+                            val=np.zeros(0), nnz=0)
+    idx = np.arange(n, dtype=np.int32)
+    hier = SimpleNamespace(system_matrix=A1, level_matrices=[A0, A1], edge_matrices=[None, None], prolongations=[P],
+                           copy_global=[np.zeros(0, dtype=np.int32), idx], copy_level=[np.zeros(0, dtype=np.int32), idx])
+    del empty
+    c = capi().Context(2)
+    c.load_hierarchy(hier)
+    c.set_smoother(kind, 0.5, 2, cheb_degree=3)
+    mg = go.OracleMG(hier, smoother=kind, omega=0.5, steps=2, cheb_degree=3)
+    u0, rhs = rng.standard_normal(n), rng.standard_normal(n)
+    ref = mg.smooth(1, u0, rhs, from_zero)
+    u, r = c.vector(n, u0), c.vector(n, rhs)
+    c.smoother_step(1, u, r, from_zero)
+    got = u.download()
+    c.close()
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+
+
 def test_more_than_256_values_falls_back_to_fp64_values():
     rng = np.random.default_rng(12)
     m = banded(3000, 27, rng)  # random values: thousands of distinct doubles
