@@ -64,6 +64,12 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8)
     args = ap.parse_args()
 
+    # stdout carries exactly one line (the JSON of rank 0): whatever libraries print while the job runs
+    # (RCCL prints a version banner at communicator creation) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -195,7 +201,8 @@ def main():
                             else "replicated (too small to pay three collectives per coarse iteration), levels >= 1 replicated")))},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     p.close()
     if launched:
         dist.barrier()
