@@ -237,9 +237,12 @@ def test_single_rank_communicator_path(hier45):
     c.close()
 
 
-@pytest.mark.parametrize("blocks", [3, 16])
-def test_block_ssor_matches_oracle_bit_exact(hier3, blocks):
-    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks)."""
+@pytest.mark.parametrize("blocks,packed", [(3, True), (16, True), (1, False), (3, False)])
+def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, packed, monkeypatch):
+    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks); with and
+    without the LDS-resident variant (blocks of more than 16 k rows sweep through global memory)."""
+    if not packed:
+        monkeypatch.setenv("GMG_DISABLE_SGS_PACKED", "1")
     level = 4
     n = hier3.level_matrices[level].n_rows
     rng = np.random.default_rng(7)
@@ -255,5 +258,5 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks):
         c.smoother_step(level, u, r, from_zero)
         assert np.array_equal(u.download(), ref)
     exact = go.OracleMG(hier3, smoother=go.SSOR).smooth(level, u0, rhs, True)
-    assert not np.array_equal(exact, mg.smooth(level, u0, rhs, True))  # the blocks really decouple
+    assert (blocks == 1) == np.array_equal(exact, mg.smooth(level, u0, rhs, True))  # the blocks really decouple
     c.close()
