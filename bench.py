@@ -169,7 +169,10 @@ def main():
                 "layout_bytes_per_launch": int(moved), "pattern_slices": [int(st.spmv0_pattern_slices), int(st.spmv0_slices)], "achieved_layout": round(moved / t_k / 1e9, 1),
                 "frac_layout": round(moved / t_k / 1e9 / HBM_PEAK_GBS, 4), "measured_stream_read_GBps": round(hbm_read, 1),
                 "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),
-                "launches_sampled": int(st.spmv0_samples)}
+                "launches_sampled": int(st.spmv0_samples),
+                # iterations enqueued ahead of the host's convergence check return at once (~1 us per kernel): a
+                # rocprofv3 --stats average over ALL launches of the kernel is lower than avg_launch_us by this share
+                "noop_launch_share": round(1.0 - st.coarse_iterations / max(1, st.coarse_enqueued), 4)}
         if st.cgupd_samples > 0:
             t_u = st.cgupd_ms_total / st.cgupd_samples * 1e-3
             # fused variant: x += alpha d and g += alpha h in one kernel (48 N); three-kernel variant: g only (24 N),

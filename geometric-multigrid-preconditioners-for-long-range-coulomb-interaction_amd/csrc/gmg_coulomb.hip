@@ -696,7 +696,7 @@ int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
       if (e == hipSuccess) break;
       if (e != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
     }
-    if (ctx->st_host[slot].done) { ctx->st_final = ctx->st_host[slot]; break; }
+    if (ctx->st_host[slot].done) { ctx->st_final = ctx->st_host[slot]; ctx->stats.coarse_enqueued += launched; break; }
     if (launched > maxit + 2 * later + 2) return fail(ctx, GMG_ERR_HIP, "coarse CG state machine did not terminate");
     if (!speculate) CHK(launch_chunk(later, slot ^ 1));
     slot ^= 1;

@@ -1309,9 +1309,19 @@ void LaplaceProblem<dim>::postprocess_error_in_energy_norm() {
 template <int dim>
 int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
   pcout("Cycle " + std::to_string(cycle) + ":");
+  // STEP50_TIMING=1: wall time of the host phases on stderr (the reference's TimerOutput sections, :1463-1560)
+  static const bool timing = std::getenv("STEP50_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[step50] cycle %u %-22s %8.3f s\n", cycle, what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   densities_on_device = on_device && par.densities_on_device;
   if (cycle == 0) make_initial_grid();
   else refine_grid(cycle);
+  lap("mesh");
   reports.emplace_back();
   CycleReport &rep = reports.back();
   rep.cycle = (int)cycle;
@@ -1328,15 +1338,22 @@ int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
     s += std::to_string(rep.dofs_by_level.back()) + (l == triangulation.n_levels() - 1 ? ")" : ", ");
   }
   pcout(s);
+  lap("setup_system");
   assemble_system();
+  lap("assemble_system");
   if (par.PreconditionerType == "GMG") assemble_multigrid();
+  lap("assemble_multigrid");
   build_transfer();
+  lap("build_transfer");
   if (!on_device) return GMG_OK;
   int rc = upload();
+  lap("upload");
   if (rc != GMG_OK) return rc;
   rc = solve();
+  lap("solve");
   if (rc != GMG_OK) return rc;
   finish_cycle();
+  lap("estimate + mark");
   return GMG_OK;
 }
 

@@ -177,6 +177,7 @@ typedef struct gmg_stats {
   int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) */
   int64_t spmv0_matrix_bytes;   /* bytes of the level-0 operator one SpMV streams in its device layout */
   int64_t spmv0_pattern_slices, spmv0_slices; /* slices served by a column pattern / all slices */
+  int64_t coarse_enqueued;      /* coarse iterations enqueued, incl. those that returned at once after convergence */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
