@@ -142,7 +142,10 @@ def main():
     n0, nnz0 = st.spmv0_rows, st.spmv0_nnz
     roof = None
     if st.spmv0_samples > 0:
+        # HIP start / stop events attached to the dispatch (hipExtLaunchKernelGGL): the kernel's own duration, as
+        # rocprofv3 --kernel-trace reports it; launches that returned at once after convergence are kept apart
         t_k = st.spmv0_ms_total / st.spmv0_samples * 1e-3
+        t_noop = st.spmv0_noop_ms_total / st.spmv0_noop_samples * 1e-3 if st.spmv0_noop_samples else None
         # fused variant: SpMV + direction update in one kernel = SpMV bytes + 16 N (reads g, writes d);
         # unfused variant (large level 0): plain SpMV + partial d.h
         fused = st.coarse_variant == 1
@@ -169,7 +172,8 @@ def main():
                 "layout_bytes_per_launch": int(moved), "pattern_slices": [int(st.spmv0_pattern_slices), int(st.spmv0_slices)], "achieved_layout": round(moved / t_k / 1e9, 1),
                 "frac_layout": round(moved / t_k / 1e9 / HBM_PEAK_GBS, 4), "measured_stream_read_GBps": round(hbm_read, 1),
                 "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),
-                "launches_sampled": int(st.spmv0_samples),
+                "launches_sampled": int(st.spmv0_samples), "noop_launches_sampled": int(st.spmv0_noop_samples),
+                "avg_noop_launch_us": None if t_noop is None else round(t_noop * 1e6, 2),
                 # iterations enqueued ahead of the host's convergence check return at once (~1 us per kernel): a
                 # rocprofv3 --stats average over ALL launches of the kernel is lower than avg_launch_us by this share
                 "noop_launch_share": round(1.0 - st.coarse_iterations / max(1, st.coarse_enqueued), 4)}

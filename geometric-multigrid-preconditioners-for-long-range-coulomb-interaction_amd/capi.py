@@ -38,7 +38,8 @@ class Stats(C.Structure):
                 ("spmv0_samples", C.c_int64), ("spmv0_ms_total", C.c_double), ("spmv0_rows", C.c_int64),
                 ("spmv0_nnz", C.c_int64), ("cgupd_samples", C.c_int64), ("cgupd_ms_total", C.c_double),
                 ("coarse_variant", C.c_int64), ("spmv0_layout", C.c_int64), ("spmv0_matrix_bytes", C.c_int64),
-                ("spmv0_pattern_slices", C.c_int64), ("spmv0_slices", C.c_int64), ("coarse_enqueued", C.c_int64)]
+                ("spmv0_pattern_slices", C.c_int64), ("spmv0_slices", C.c_int64), ("coarse_enqueued", C.c_int64),
+                ("spmv0_noop_samples", C.c_int64), ("spmv0_noop_ms_total", C.c_double)]
 
 
 class GMGError(RuntimeError):

@@ -8,6 +8,7 @@
 // :938-1017 as restated in SURVEY.md 3.2.
 #include "../../include/gmg_coulomb.h"
 #include "gmg_device.hpp"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -120,6 +121,7 @@ struct gmg_context {
   std::vector<hipEvent_t> ev_a, ev_b;  // sampled level-0 SpMV launches
   std::vector<hipEvent_t> ev_c, ev_d;  // sampled update-kernel launches
   int ev_used = 0, ev2_used = 0;
+  hipEvent_t timed_start = nullptr, timed_stop = nullptr;  // next launch carries these as its dispatch start / stop events
   gmg_stats stats{};
   Comm comm;
   bool dist = false;             // communicator initialised: level 0 + system rows are partitioned
@@ -473,6 +475,20 @@ int alloc_vec(gmg_context *ctx, double **p, int64_t n) {
 // ---- SpMV launcher ---------------------------------------------------------------------
 
 // one launcher for both layouts; returns the grid (= number of reduction partials when CG != 0)
+// Launch on the context's stream.  When the caller armed ctx->timed_start / timed_stop the events are
+// attached to the dispatch itself (hipExtLaunchKernelGGL): hipEventElapsedTime then gives the kernel's own
+// begin-to-end time -- what rocprofv3 --kernel-trace reports -- instead of event-record to event-record,
+// which includes the launch gap.
+template <typename K, typename A>
+inline void launch_timed(gmg_context *ctx, K kernel, dim3 grid, dim3 block, size_t lds, const A &args) {
+  if (ctx->timed_start) {
+    hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, ctx->stream, ctx->timed_start, ctx->timed_stop, 0u, args);
+    ctx->timed_start = ctx->timed_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, args);
+  }
+}
+
 template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
@@ -481,16 +497,16 @@ int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
       SellPatArgs pa{};
       pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
       for (int u = 0; u < 9; ++u) pa.centre[u] = m.sellp_centre[u];
-      hipLaunchKernelGGL((spmv_sellp_kernel<MODE, CG>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, pa);
+      launch_timed(ctx, spmv_sellp_kernel<MODE, CG>, dim3(m.sell_grid), dim3(kThreads), 0, pa);
       return m.sell_grid;
     }
-    if (m.val8 && m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
-    else if (m.val8) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, true, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
-    else if (m.col16) hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, true>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
-    else hipLaunchKernelGGL((spmv_sell_kernel<MODE, CG, false, false>), dim3(m.sell_grid), dim3(kThreads), 0, ctx->stream, sa);
+    if (m.val8 && m.col16) launch_timed(ctx, spmv_sell_kernel<MODE, CG, true, true>, dim3(m.sell_grid), dim3(kThreads), 0, sa);
+    else if (m.val8) launch_timed(ctx, spmv_sell_kernel<MODE, CG, true, false>, dim3(m.sell_grid), dim3(kThreads), 0, sa);
+    else if (m.col16) launch_timed(ctx, spmv_sell_kernel<MODE, CG, false, true>, dim3(m.sell_grid), dim3(kThreads), 0, sa);
+    else launch_timed(ctx, spmv_sell_kernel<MODE, CG, false, false>, dim3(m.sell_grid), dim3(kThreads), 0, sa);
     return m.sell_grid;
   }
-  hipLaunchKernelGGL((spmv_tile_kernel<MODE, CG>), dim3(m.grid), dim3(kThreads), 0, ctx->stream, a);
+  launch_timed(ctx, spmv_tile_kernel<MODE, CG>, dim3(m.grid), dim3(kThreads), 0, a);
   return m.grid;
 }
 template <int MODE>
@@ -644,17 +660,26 @@ int smooth_level(gmg_context *ctx, int l, double **u_io, const double *rhs, bool
   return GMG_OK;
 }
 
+// Sample i brackets iteration i * prof_every of the solve just finished.  Iterations at or beyond the
+// converged count returned at once: their event time is the cost of the bracket itself (launch gap +
+// an early-exit kernel) and is kept apart, so that bench.py can take it off the live launches.
 void collect_profile_samples(gmg_context *ctx) {
+  const int iters = ctx->st_final.iters;
   for (int i = 0; i < ctx->ev_used; ++i) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_a[(size_t)i], ctx->ev_b[(size_t)i]) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, ctx->ev_a[(size_t)i], ctx->ev_b[(size_t)i]) != hipSuccess) continue;
+    if (i * ctx->prof_every < iters) {
       ctx->stats.spmv0_ms_total += ms;
       ctx->stats.spmv0_samples++;
+    } else {
+      ctx->stats.spmv0_noop_ms_total += ms;
+      ctx->stats.spmv0_noop_samples++;
     }
   }
   for (int i = 0; i < ctx->ev2_used; ++i) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_c[(size_t)i], ctx->ev_d[(size_t)i]) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, ctx->ev_c[(size_t)i], ctx->ev_d[(size_t)i]) != hipSuccess) continue;
+    if (i * ctx->prof_every < iters) {
       ctx->stats.cgupd_ms_total += ms;
       ctx->stats.cgupd_samples++;
     }
@@ -739,14 +764,12 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
     a.part_out = ctx->part_a;
     a.tol = ctx->coarse_tol; a.maxit = maxit;
     const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
-    if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
+    if (sample) { ctx->timed_start = ctx->ev_a[(size_t)ctx->ev_used]; ctx->timed_stop = ctx->ev_b[(size_t)ctx->ev_used++]; }
     const int n_part_dh = launch_op<kStore, 1>(ctx, A, a);
-    if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
     CGUpdateArgs ua{x, ctx->cg_g, a.dnew, ctx->cg_h, n, ctx->st, ctx->part_a, n_part_dh, ctx->part_b};
     const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
-    if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
-    if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+    if (sample2) { ctx->timed_start = ctx->ev_c[(size_t)ctx->ev2_used]; ctx->timed_stop = ctx->ev_d[(size_t)ctx->ev2_used++]; }
+    launch_timed(ctx, cg_update_kernel, dim3(g_upd), dim3(kThreads), 0, ua);
     n_part_gg = g_upd;
     return GMG_OK;
   }));

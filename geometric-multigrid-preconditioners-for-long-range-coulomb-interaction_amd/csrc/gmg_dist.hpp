@@ -61,9 +61,8 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
     a.st = ctx->st;
     a.part_out = ctx->part_a;
     const bool sample = ctx->prof_every > 0 && (launched % ctx->prof_every) == 0 && ctx->ev_used < (int)ctx->ev_a.size();
-    if (sample) (void)hipEventRecord(ctx->ev_a[(size_t)ctx->ev_used], ctx->stream);
+    if (sample) { ctx->timed_start = ctx->ev_a[(size_t)ctx->ev_used]; ctx->timed_stop = ctx->ev_b[(size_t)ctx->ev_used++]; }
     const int n_part_dh = launch_op<kStore, 2>(ctx, A, a);
-    if (sample) (void)hipEventRecord(ctx->ev_b[(size_t)ctx->ev_used++], ctx->stream);
     const double *dh_src = ctx->part_a;
     int dh_n = n_part_dh;
     if (comm) {
@@ -73,9 +72,8 @@ int coarse_solve_unfused(gmg_context *ctx, double *x, const double *b, int *iter
     }
     CGUpdateGArgs ua{ctx->cg_g, ctx->cg_h, n, ctx->st, dh_src, dh_n, ctx->part_b};
     const bool sample2 = sample && ctx->ev2_used < (int)ctx->ev_c.size();
-    if (sample2) (void)hipEventRecord(ctx->ev_c[(size_t)ctx->ev2_used], ctx->stream);
-    hipLaunchKernelGGL(cg_update_g_kernel, dim3(g_upd), dim3(kThreads), 0, ctx->stream, ua);
-    if (sample2) (void)hipEventRecord(ctx->ev_d[(size_t)ctx->ev2_used++], ctx->stream);
+    if (sample2) { ctx->timed_start = ctx->ev_c[(size_t)ctx->ev2_used]; ctx->timed_stop = ctx->ev_d[(size_t)ctx->ev2_used++]; }
+    launch_timed(ctx, cg_update_g_kernel, dim3(g_upd), dim3(kThreads), 0, ua);
     if ((launched + 1) % kXRing == 0) flush_x(launched + 1 - kXRing, launched + 1);
     if (comm) {
       hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, (const double *)ctx->part_b, g_upd, 1, 0u, s_gg);

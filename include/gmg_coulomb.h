@@ -168,7 +168,7 @@ typedef struct gmg_stats {
   int64_t coarse_solves;        /* calls of the coarse solver since the last reset           */
   int64_t coarse_iterations;    /* inner CG iterations summed over those calls               */
   int64_t vcycles;
-  int64_t spmv0_samples;        /* level-0 SpMV launches bracketed by HIP events             */
+  int64_t spmv0_samples;        /* live level-0 SpMV launches bracketed by HIP events        */
   double spmv0_ms_total;        /* summed event time of those launches                       */
   int64_t spmv0_rows, spmv0_nnz; /* shape of the level-0 operator (for algorithmic bytes)    */
   int64_t cgupd_samples;
@@ -178,10 +178,12 @@ typedef struct gmg_stats {
   int64_t spmv0_matrix_bytes;   /* bytes of the level-0 operator one SpMV streams in its device layout */
   int64_t spmv0_pattern_slices, spmv0_slices; /* slices served by a column pattern / all slices */
   int64_t coarse_enqueued;      /* coarse iterations enqueued, incl. those that returned at once after convergence */
+  int64_t spmv0_noop_samples;   /* sampled level-0 launches that returned at once (after convergence): ...    */
+  double spmv0_noop_ms_total;   /* ... their summed event time                                                */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
-/* bracket every `sample_every`-th level-0 SpMV launch with HIP events (0 = off).           */
+/* attach HIP start / stop events to every `sample_every`-th level-0 SpMV launch (0 = off).  */
 int gmg_set_profiling(gmg_context *ctx, int sample_every);
 /* streaming-read and copy bandwidth of this device (GB/s) on n_bytes per array: the measured
  * ceiling bench.py prints beside the 8 TB/s spec peak.                                    */
