@@ -402,7 +402,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       m.sell = true;
       m.n_slices = (int)n_slices;
       m.sell_quads = quads;
-      // one wave per >= 1 slice; at most 1024 workgroups (4 per CU)
+      // one wave per >= 1 slice; at most kMaxPartials workgroups (one reduction partial each)
       const int per_xcd = (int)((n_slices + 7) / 8);
       m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
       if (const char *g = std::getenv("GMG_SELL_GRID")) m.sell_grid = std::max(8, std::atoi(g) / 8 * 8);

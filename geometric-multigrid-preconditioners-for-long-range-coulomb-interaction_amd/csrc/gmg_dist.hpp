@@ -5,9 +5,11 @@
 //     between the direction update and the SpMV; every reduction goes workgroup partials ->
 //     one device scalar -> ncclAllReduce (sum, fp64, count 1) -> read by the next kernel as a
 //     one-element "partials" array.  No host synchronisation inside a chunk of iterations.
-//   * large single-GPU level 0 (>= kUnfusedMinRows): the fused kernel gathers d AND g per
-//     nonzero, which costs more (TA-bound, measured 149 vs 117+9 us at 121^3) than streaming
-//     24 N bytes once; small problems keep the fused 2-kernel iteration (launch-bound).
+//   * large single-GPU level 0 (>= kUnfusedMinRows): the fused kernel reads d AND g for every
+//     operand, which costs more vector-load issue than streaming 24 N bytes once (81^3 level 0:
+//     22.3 vs 15.9 ms per solve); small problems keep the fused 2-kernel iteration (launch-bound).
+// The update kernel of this variant touches g only; x += alpha d is applied kXRing iterations at
+// a time from a ring of direction vectors (cg_xflush_kernel): same additions in the same order.
 // Included by gmg_coulomb.hip.
 #pragma once
 
