@@ -37,7 +37,7 @@ def build_device(force=False, verbose=False):
     if force or _newer(LIB_DEVICE, srcs):
         cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-std=c++17",
                "-Wall", "-Wno-unused-function", "-o", LIB_DEVICE, os.path.join(CSRC, "gmg_coulomb.hip"),
-               "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+               "-pthread", "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

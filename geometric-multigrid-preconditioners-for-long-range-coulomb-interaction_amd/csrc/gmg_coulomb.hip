@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <climits>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -193,6 +195,28 @@ void free_csr(DevCSR &m) {
 }
 
 // Host CSR -> device CSR + LDS-window tiling.
+// Host-side setup loops (layout conversion of 10^7..10^8 nonzeros) run on a few threads: f(begin, end, chunk)
+inline int host_threads() {
+  static const int n = [] {
+    const char *e = std::getenv("GMG_HOST_THREADS");
+    int t = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(16, t));
+  }();
+  return n;
+}
+template <class F>
+void parallel_chunks(int64_t n, F f) {
+  const int nt = host_threads();
+  if (n < 2048 || nt <= 1) { f((int64_t)0, n, 0); return; }
+  const int64_t per = (n + nt - 1) / nt;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = t * per, e = std::min(n, b + per);
+    if (b < e) th.emplace_back(f, b, e, t);
+  }
+  for (auto &x : th) x.join();
+}
+
 int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col,
                const double *val, bool keep_csr = false) {
   if (n_rows < 0 || n_cols < 0 || !rowptr) return fail(ctx, GMG_ERR_INVALID, "upload_csr: bad arguments");
@@ -204,6 +228,14 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   free_csr(m);
   m.halo = keep;
   m.n_rows = n_rows; m.n_cols = n_cols; m.nnz = nnz;
+  static const bool dbg_upload = std::getenv("GMG_DEBUG_UPLOAD") != nullptr;
+  auto t_phase = std::chrono::steady_clock::now();
+  auto phase = [&](const char *what) {
+    if (!dbg_upload) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[gmg]   upload %-14s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+    t_phase = now;
+  };
   std::vector<int32_t> rp((size_t)n_rows + 1);
   for (int64_t i = 0; i <= n_rows; ++i) {
     if (i && rowptr[i] < rowptr[i - 1]) return fail(ctx, GMG_ERR_INVALID, "rowptr not monotone");
@@ -244,6 +276,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   HIPC(hipMemcpyAsync(m.tile_row, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));  // host staging buffers die here
   m.valid = true;
+  phase("csr copy");
   // SELL-64 copy when the rows are regular enough (level-0 lattice, active-mesh matrix)
   const char *no_sell = std::getenv("GMG_DISABLE_SELL");
   if (n_rows >= 1024 && !(no_sell && no_sell[0] == '1')) {
@@ -260,10 +293,15 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
     std::vector<std::vector<int32_t>> patterns;
     std::map<std::vector<int32_t>, int> pattern_id;
     int64_t quads = 0;
-    for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
-      int64_t w = 0;
-      for (int64_t r2 = sidx * 64; r2 < std::min<int64_t>(n_rows, sidx * 64 + 64); ++r2) w = std::max(w, rowptr[r2 + 1] - rowptr[r2]);
-      if (allow_pat && sidx * 64 + 64 <= n_rows) {
+    // per slice (parallel): widest row, and the sorted union of (col - row) when the slice qualifies
+    std::vector<int32_t> slice_w((size_t)n_slices, 0);
+    std::vector<std::vector<int32_t>> slice_delta((size_t)n_slices);
+    parallel_chunks(n_slices, [&](int64_t sb, int64_t se, int) {
+      for (int64_t sidx = sb; sidx < se; ++sidx) {
+        int64_t w = 0;
+        for (int64_t r2 = sidx * 64; r2 < std::min<int64_t>(n_rows, sidx * 64 + 64); ++r2) w = std::max(w, rowptr[r2 + 1] - rowptr[r2]);
+        slice_w[(size_t)sidx] = (int32_t)w;
+        if (!(allow_pat && sidx * 64 + 64 <= n_rows)) continue;
         std::vector<int32_t> delta;
         for (int64_t r2 = sidx * 64; r2 < sidx * 64 + 64 && delta.size() <= 32; ++r2)
           for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) {
@@ -276,17 +314,23 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
         // columns must be strictly ascending inside each row for the positions to be well defined
         for (int64_t r2 = sidx * 64; ok && r2 < sidx * 64 + 64; ++r2)
           for (int64_t k = rowptr[r2] + 1; k < rowptr[r2 + 1]; ++k) ok = ok && col[k] > col[k - 1];
-        if (ok && (int64_t)delta.size() <= ((w + 3) / 4) * 4 + 4) {
-          auto ins = pattern_id.emplace(delta, (int)patterns.size());
-          if (ins.second) patterns.push_back(delta);
-          spat[(size_t)sidx] = ins.first->second;
-          w = (int64_t)delta.size();
-        }
+        if (ok && (int64_t)delta.size() <= ((w + 3) / 4) * 4 + 4) slice_delta[(size_t)sidx] = std::move(delta);
+      }
+    });
+    for (int64_t sidx = 0; sidx < n_slices; ++sidx) {  // pattern ids in slice order
+      int64_t w = slice_w[(size_t)sidx];
+      if (!slice_delta[(size_t)sidx].empty()) {
+        auto ins = pattern_id.emplace(slice_delta[(size_t)sidx], (int)patterns.size());
+        if (ins.second) patterns.push_back(slice_delta[(size_t)sidx]);
+        spat[(size_t)sidx] = ins.first->second;
+        w = (int64_t)slice_delta[(size_t)sidx].size();
       }
       quads += (w + 3) / 4;
       sp[(size_t)sidx + 1] = (int32_t)quads;
     }
+    slice_delta.clear();
     if (quads * 256 <= (int64_t)(1.12 * (double)nnz) && quads * 256 < ((int64_t)1 << 31)) {
+      phase("patterns");
       // --- value dictionary (bit patterns, so -0.0 / NaN payloads survive)
       const char *no_comp = std::getenv("GMG_DISABLE_COMPRESSION");
       const bool allow_comp = !(no_comp && no_comp[0] == '1');
@@ -295,29 +339,72 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       bool val8 = allow_comp;
       code_of.emplace(0ull, 0);  // +0.0 is the padding value: always code 0
       dict.push_back(0.0);
-      for (int64_t k = 0; k < nnz && val8; ++k) {
-        uint64_t bits;
-        std::memcpy(&bits, &val[k], 8);
-        if (code_of.emplace(bits, (int)dict.size()).second) {
-          dict.push_back(val[k]);
-          if (dict.size() > 256) val8 = false;
+      if (val8) {
+        // distinct bit patterns in order of first occurrence: per chunk in parallel, merged in chunk order
+        std::vector<std::vector<uint64_t>> firsts((size_t)host_threads());
+        std::vector<char> overflow((size_t)host_threads(), 0);
+        parallel_chunks(nnz, [&](int64_t kb, int64_t ke, int t) {
+          std::unordered_map<uint64_t, int> seen;
+          uint64_t last = ~0ull;
+          for (int64_t k = kb; k < ke; ++k) {
+            uint64_t bits;
+            std::memcpy(&bits, &val[k], 8);
+            if (bits == last) continue;
+            last = bits;
+            if (seen.emplace(bits, 0).second) {
+              firsts[(size_t)t].push_back(bits);
+              if (firsts[(size_t)t].size() > 256) { overflow[(size_t)t] = 1; return; }
+            }
+          }
+        });
+        for (size_t t = 0; t < firsts.size() && val8; ++t) {
+          if (overflow[t]) val8 = false;
+          for (uint64_t bits : firsts[t]) {
+            if (!val8) break;
+            if (code_of.emplace(bits, (int)dict.size()).second) {
+              double v;
+              std::memcpy(&v, &bits, 8);
+              dict.push_back(v);
+              if (dict.size() > 256) val8 = false;
+            }
+          }
         }
       }
+      // read-only open-addressing table for the packing threads
+      std::vector<uint64_t> ht_key(1024, 0);
+      std::vector<int16_t> ht_code(1024, -1);
+      auto ht_slot = [](uint64_t bits) { return (size_t)((bits * 0x9E3779B97F4A7C15ull) >> 54); };
+      if (val8)
+        for (const auto &kv : code_of) {
+          size_t h = ht_slot(kv.first);
+          while (ht_code[h] >= 0) h = (h + 1) & 1023;
+          ht_key[h] = kv.first; ht_code[h] = (int16_t)kv.second;
+        }
+      auto code_lookup = [&](uint64_t bits) -> uint8_t {
+        size_t h = ht_slot(bits);
+        while (ht_key[h] != bits || ht_code[h] < 0) h = (h + 1) & 1023;
+        return (uint8_t)ht_code[h];
+      };
+      phase("dictionary");
       // --- per-slice column base, 16-bit offsets if every slice spans < 65536 columns
       std::vector<int32_t> sbase((size_t)n_slices, 0);
-      bool col16 = allow_comp;
-      for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
-        int64_t lo = INT64_MAX, hi = -1;
-        const int64_t rend = std::min<int64_t>(n_rows, sidx * 64 + 64);
-        for (int64_t r2 = sidx * 64; r2 < rend; ++r2) {
-          lo = std::min(lo, r2 < n_cols ? r2 : lo);  // the padding column is the row itself
-          hi = std::max(hi, r2 < n_cols ? r2 : hi);
-          for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) { lo = std::min<int64_t>(lo, col[k]); hi = std::max<int64_t>(hi, col[k]); }
+      std::vector<char> wide((size_t)host_threads(), 0);
+      parallel_chunks(n_slices, [&](int64_t sb, int64_t se, int t) {
+        for (int64_t sidx = sb; sidx < se; ++sidx) {
+          int64_t lo = INT64_MAX, hi = -1;
+          const int64_t rend = std::min<int64_t>(n_rows, sidx * 64 + 64);
+          for (int64_t r2 = sidx * 64; r2 < rend; ++r2) {
+            lo = std::min(lo, r2 < n_cols ? r2 : lo);  // the padding column is the row itself
+            hi = std::max(hi, r2 < n_cols ? r2 : hi);
+            for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) { lo = std::min<int64_t>(lo, col[k]); hi = std::max<int64_t>(hi, col[k]); }
+          }
+          if (hi < 0) { lo = hi = 0; }
+          sbase[(size_t)sidx] = (int32_t)lo;
+          if (hi - lo > 65535) wide[(size_t)t] = 1;
         }
-        if (hi < 0) { lo = hi = 0; }
-        sbase[(size_t)sidx] = (int32_t)lo;
-        if (hi - lo > 65535) col16 = false;
-      }
+      });
+      bool col16 = allow_comp;
+      for (char wflag : wide) col16 = col16 && !wflag;
       const size_t n_ent = (size_t)quads * 256;
       int n_pattern_slices = 0;
       for (int32_t v : spat) n_pattern_slices += v >= 0;
@@ -325,7 +412,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       std::vector<uint8_t> v1(val8 ? n_ent : 0, 0);
       std::vector<int32_t> c4(col16 ? 0 : n_ent, 0);
       std::vector<uint16_t> c2(col16 ? n_ent : 0, 0);
-      for (int64_t sidx = 0; sidx < n_slices; ++sidx) {
+      parallel_chunks(n_slices, [&](int64_t sb, int64_t se, int) {
+      for (int64_t sidx = sb; sidx < se; ++sidx) {
         const int64_t q0 = sp[(size_t)sidx], nq = sp[(size_t)sidx + 1] - q0;
         for (int lane = 0; lane < 64; ++lane) {
           const int64_t r2 = sidx * 64 + lane;
@@ -347,13 +435,14 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
               cj = (j < len && !debug_nogather) ? col[k0 + j] : padcol;
               vj = j < len ? val[k0 + j] : 0.0;
             }
-            if (val8) { uint64_t bits; std::memcpy(&bits, &vj, 8); v1[oc] = (uint8_t)code_of.at(bits); }
+            if (val8) { uint64_t bits; std::memcpy(&bits, &vj, 8); v1[oc] = code_lookup(bits); }
             else v2[ov] = vj;
             if (col16) c2[oc] = (uint16_t)(cj - sbase[(size_t)sidx]);
             else c4[oc] = cj;
           }
         }
       }
+      });
       dict.resize(256, 0.0);
       HIPC(hipMalloc(&m.slice_ptr, sizeof(int32_t) * sp.size()));
       HIPC(hipMalloc(&m.slice_base, sizeof(int32_t) * sbase.size()));
@@ -402,6 +491,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       m.sell = true;
       m.n_slices = (int)n_slices;
       m.sell_quads = quads;
+      phase("sell pack+copy");
       // one wave per >= 1 slice; at most kMaxPartials workgroups (one reduction partial each)
       const int per_xcd = (int)((n_slices + 7) / 8);
       m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
@@ -440,6 +530,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       }
     }
   }
+  phase("finish");
   if (std::getenv("GMG_DEBUG_UPLOAD"))
     std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d patterns %d pattern_slices %d/%d\n", (long long)n_rows,
                  (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid, m.n_patterns, m.n_pattern_slices, m.n_slices);
