@@ -153,6 +153,33 @@ def test_invalid_operator_is_rejected():
     c.close()
 
 
+@pytest.mark.parametrize("nacl,log", [(3, "cluster/SSOR_run"), (5, "cluster/SSOR_run"), (7, "cluster/SSOR_run"), (10, "cluster/SSOR_run"),
+                                      (5, "cluster/without_opti"), (10, "cluster/without_opti")])
+def test_cluster_runs_cycle0(golden, nacl, log):
+    """Cycle 0 of the reference's cluster runs between the 8-atom and the 64k-atom case (BASELINE configs 3
+    and 4 among them: 1000 and 8000 atoms; 53^3 .. 81^3 level 0), with and without the rhs cutoff lists
+    ('Flag for RHS evaluation optimization'): every printed digit of the solve.  The single level makes the
+    smoother irrelevant; the coarse CG is the fused variant below 200 k rows, the three-kernel one above."""
+    from conftest import rel_close
+
+    run = next(r for r in golden[log]["runs"] if r.get("n_atoms") == 8 * nacl ** 3)
+    g = run["cycles"][0]
+    S = pkg().step50
+    p = S.Problem(S.prm_text(left=0, right=nacl, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+                             cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=log.endswith("SSOR_run"), quad_rhs=1,
+                             global_refinement=0, smoother="Jacobi"))
+    p.set_nacl_atoms(nacl)
+    r = p.run_cycle(0, on_device=True)
+    assert r["active_cells"] == g["active_cells"] and r["dofs_by_level"] == g["dofs_by_level"]
+    assert r["cg_iterations"] == g["cg_iterations"] == 1
+    assert abs(r["starting_value"] - g["starting_value"]) < 0.6e-6
+    assert abs(r["convergence_value"] - g["convergence_value"]) <= 1e-4 * g["convergence_value"]
+    for k in ("sol_l1", "sol_l2", "sol_linf", "rhs_l2"):
+        if k in g:
+            assert rel_close(r[k], g[k], 11), (k, r[k], g[k])
+    p.close()
+
+
 @pytest.fixture(scope="module")
 def full_size():
     """BASELINE config 5, cycle 0: 121^3 level 0 (1 771 561 rows, 47 045 881 nnz) on the host."""
