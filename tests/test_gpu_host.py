@@ -159,3 +159,10 @@ def test_cli_output_diffs_against_reference_output_file(golden_dir, tmp_path):
             assert abs(a - b) <= tol * max(abs(b), 1e-300) or abs(a - b) < 1e-12, (k, a, b)
     missing = sorted({k[1] for k in ref if k not in ours})
     assert missing == [], missing
+
+
+def test_rhs_cutoff_lists_on_device_match_reference_error_table(golden, golden_dir):
+    """The same error-versus-cutoff table with the charge densities evaluated by charge_density_kernel."""
+    from test_host import check_rc_variation
+
+    check_rc_variation(golden, golden_dir, on_device=True)

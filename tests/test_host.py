@@ -128,3 +128,49 @@ def test_host_two_atom_exact_bc_golden(golden, golden_dir):
     assert rel_close(float(np.abs(b).max()), g["rhs_linf"], 11)
     A = h.system_matrix
     assert rel_close(float(np.sqrt((A.val ** 2).sum())), g["matrix_frobenius"], 11)
+
+
+def _rc_variation_rhs(golden_dir, optimized, cutoff, on_device=False):
+    """The setup of the reference's tests_rhs_rc_variation (2 atoms, [-2.5, 2.5]^3 in 16^3 cells, homogeneous
+    boundary values, QGauss(2) for the rhs): returns (|b|_2, |b|_inf) of the assembled right-hand side."""
+    S = pkg().step50
+    p = S.Problem(S.prm_text(left=-2.5, right=2.5, mesh_size=0.3125, vacuum=0, problem="GaussianCharges", dim=3, bc="Homogeneous",
+                             cycles=1, r_c=0.5, cutoff=cutoff, rhs_optimization=optimized, quad_rhs=1, global_refinement=0,
+                             smoother="Jacobi", densities_on_device=on_device))
+    p.read_lammps(os.path.join(golden_dir, "atom_2.data"))
+    p.run_cycle(0, on_device=on_device)
+    b = p.hierarchy().system_rhs
+    return float(np.sqrt(b @ b)), float(np.abs(b).max())
+
+
+def _cutoff_table(golden_dir, name):
+    rows = {}
+    with open(os.path.join(golden_dir, name)) as fh:
+        for line in fh:
+            parts = line.split()
+            if len(parts) == 2 and parts[0][0].isdigit():
+                rows[float(parts[0])] = float(parts[1])
+    return rows
+
+
+def check_rc_variation(golden, golden_dir, on_device):
+    g = golden["tests_rhs_rc_variation/rc_variation.mpirun=1"]["runs"][0]["cycles"][0]
+    l2, linf = _rc_variation_rhs(golden_dir, False, 3.0, on_device)
+    assert rel_close(l2, g["rhs_l2"], 11) and rel_close(linf, g["rhs_linf"], 11)
+    t2 = _cutoff_table(golden_dir, "RHS_Norm_value_comparison_L2.dat")
+    ti = _cutoff_table(golden_dir, "RHS_Norm_value_comparison_Linf.dat")
+    assert len(t2) == len(ti) == 17
+    for cutoff in sorted(t2):
+        if cutoff > 4.5:  # both tables print 0.000000000000 from there on
+            continue
+        o2, oi = _rc_variation_rhs(golden_dir, True, cutoff, on_device)
+        # the tables carry 10 decimals, of which the reference printed 7 significant digits
+        assert abs(abs(o2 - l2) - t2[cutoff]) <= 1.5e-10 + 1e-6 * t2[cutoff], (cutoff, abs(o2 - l2), t2[cutoff])
+        assert abs(abs(oi - linf) - ti[cutoff]) <= 1.5e-10 + 1e-6 * ti[cutoff], (cutoff, abs(oi - linf), ti[cutoff])
+
+
+def test_rhs_cutoff_lists_match_reference_error_table(golden, golden_dir):
+    """SURVEY 8(f) N1 goldens: the rhs norms of tests_rhs_rc_variation/*.output, and for every cutoff
+    2.0 .. 4.5 the absolute difference of the rhs norms with and without the per-cell atom lists
+    (src/step-50.cc:260-306) as tabulated in Plotting/RHS_Norm_value_comparison_{L2,Linf}.dat."""
+    check_rc_variation(golden, golden_dir, on_device=False)
