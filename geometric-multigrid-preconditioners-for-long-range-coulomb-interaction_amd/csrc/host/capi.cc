@@ -177,6 +177,12 @@ int step50_get_vector(step50_problem *h, int which, double *out) {
   std::memcpy(out, v.data(), sizeof(double) * v.size());
   return 0;
 }
+// check vector of the reference's rhs test: per DoF, the integrated charge density of its cells
+int step50_total_charge_density(step50_problem *h, double *out) {
+  const std::vector<double> v = DISPATCH(h, total_charge_density_vector());
+  std::memcpy(out, v.data(), sizeof(double) * v.size());
+  return 0;
+}
 int step50_dof_coordinates(step50_problem *h, double *xyz) {
   const auto &keys = DISPATCH(h, vertex_of_dof);
   for (size_t i = 0; i < keys.size(); ++i) {

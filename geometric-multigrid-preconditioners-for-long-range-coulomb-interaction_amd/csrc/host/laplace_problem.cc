@@ -1357,6 +1357,33 @@ int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
   return GMG_OK;
 }
 
+// The check vector of the reference's rhs test (tests_rhs_rc_variation/rc_variation.cc:110-215,
+// charge_density_test): every DoF of a cell receives sum_q rho(x_q) JxW_q of that cell (no shape
+// function weights), constrained DoFs receive nothing (homogeneous lines: distribute_local_to_global
+// drops them).  Uses the densities of the last assembled right-hand side.
+template <int dim>
+std::vector<double> LaplaceProblem<dim>::total_charge_density_vector() const {
+  constexpr int nv = 1 << dim;
+  std::vector<double> t(vertex_of_dof.size(), 0.0);
+  if (!lammpsinput || density_values_for_each_cell.size() != active_cells.size()) return t;
+  const Quadrature<dim> q_rhs((int)(par.degree + par.quadrature_degree_rhs));
+  for (size_t ci = 0; ci < active_cells.size(); ++ci) {
+    const ActiveCell &ac = active_cells[ci];
+    const double jxw = std::pow(triangulation.cell_size(ac.level), dim);
+    double cell_sum = 0.0;
+    for (size_t q = 0; q < q_rhs.p.size(); ++q) cell_sum += density_values_for_each_cell[ci][q] * (q_rhs.w[q] * jxw);
+    int32_t dofs[nv];
+    cell_dofs(ac, dofs);
+    for (int a = 0; a < nv; ++a) {
+      const int32_t cl = constraint_of_dof[(size_t)dofs[a]];
+      if (cl < 0) t[(size_t)dofs[a]] += cell_sum;
+      else
+        for (auto &e : constraint_lines[(size_t)cl].entries) t[(size_t)e.first] += e.second * cell_sum;
+    }
+  }
+  return t;
+}
+
 template <int dim>
 void LaplaceProblem<dim>::finish_cycle() {
   estimate_error_and_mark_cells();                                               // :1552

@@ -108,6 +108,7 @@ class LaplaceProblem {
   void refine_grid(unsigned int cycle);                                  // :1095-1121
   void postprocess_electrostatic_energy();                               // :1310-1420
   void postprocess_error_in_energy_norm();                               // :1423-1461
+  std::vector<double> total_charge_density_vector() const;               // tests_rhs_rc_variation/rc_variation.cc:110-215
   int run_cycle(unsigned int cycle, bool on_device = true);              // one iteration of the loop in run()
   void finish_cycle();                                   // estimator + energy, the tail of the loop body
   void set_solution(const std::vector<double> &x);       // test hook, see laplace_problem.cc

@@ -184,6 +184,12 @@ class Problem:
         self.L.step50_get_vector(self.h, C.c_int(w), out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
 
+    def total_charge_density(self):
+        """Per DoF, the integrated charge density of its cells (the check vector of tests_rhs_rc_variation)."""
+        out = np.zeros(self.n_dofs())
+        self.L.step50_total_charge_density(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
     def dof_coordinates(self):
         out = np.zeros((self.n_dofs(), 3))
         self.L.step50_dof_coordinates(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))

@@ -40,7 +40,9 @@ ATOM_FILES = ["tests/atom_n1_2.data", "tests/atom_2.data", "atom/atom_n1_8.data"
               # expected output of the reference's current regression test, compared line by line with ./step50_mi355x
               "tests/gaussian-charges.mpirun=1.output",
               # |rhs norm with cutoff lists - without| per cutoff (the setup of tests_rhs_rc_variation: 2 atoms, 16^3 cells)
-              "Plotting/RHS_Norm_value_comparison_L2.dat", "Plotting/RHS_Norm_value_comparison_Linf.dat"]
+              "Plotting/RHS_Norm_value_comparison_L2.dat", "Plotting/RHS_Norm_value_comparison_Linf.dat",
+              # same for the l2 norm of the per-DoF integrated charge density (rc_variation.cc: charge_density_test)
+              "Plotting/Total_charge_density_AbsErr_L2.dat"]
 
 NUM = r"([-+0-9.eE]+|nan|inf)"
 FIELDS = [

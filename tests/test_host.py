@@ -140,7 +140,8 @@ def _rc_variation_rhs(golden_dir, optimized, cutoff, on_device=False):
     p.read_lammps(os.path.join(golden_dir, "atom_2.data"))
     p.run_cycle(0, on_device=on_device)
     b = p.hierarchy().system_rhs
-    return float(np.sqrt(b @ b)), float(np.abs(b).max())
+    t = p.total_charge_density()
+    return float(np.sqrt(b @ b)), float(np.abs(b).max()), float(np.sqrt(t @ t))
 
 
 def _cutoff_table(golden_dir, name):
@@ -155,15 +156,17 @@ def _cutoff_table(golden_dir, name):
 
 def check_rc_variation(golden, golden_dir, on_device):
     g = golden["tests_rhs_rc_variation/rc_variation.mpirun=1"]["runs"][0]["cycles"][0]
-    l2, linf = _rc_variation_rhs(golden_dir, False, 3.0, on_device)
+    l2, linf, tot = _rc_variation_rhs(golden_dir, False, 3.0, on_device)
     assert rel_close(l2, g["rhs_l2"], 11) and rel_close(linf, g["rhs_linf"], 11)
     t2 = _cutoff_table(golden_dir, "RHS_Norm_value_comparison_L2.dat")
     ti = _cutoff_table(golden_dir, "RHS_Norm_value_comparison_Linf.dat")
-    assert len(t2) == len(ti) == 17
+    tt = _cutoff_table(golden_dir, "Total_charge_density_AbsErr_L2.dat")
+    assert len(t2) == len(ti) == len(tt) == 17
     for cutoff in sorted(t2):
         if cutoff > 4.5:  # both tables print 0.000000000000 from there on
             continue
-        o2, oi = _rc_variation_rhs(golden_dir, True, cutoff, on_device)
+        o2, oi, ot = _rc_variation_rhs(golden_dir, True, cutoff, on_device)
+        assert abs(abs(ot - tot) - tt[cutoff]) <= 1e-9, (cutoff, abs(ot - tot), tt[cutoff])  # printed to 1e-9
         # the tables carry 10 decimals, of which the reference printed 7 significant digits
         assert abs(abs(o2 - l2) - t2[cutoff]) <= 1.5e-10 + 1e-6 * t2[cutoff], (cutoff, abs(o2 - l2), t2[cutoff])
         assert abs(abs(oi - linf) - ti[cutoff]) <= 1.5e-10 + 1e-6 * ti[cutoff], (cutoff, abs(oi - linf), ti[cutoff])
@@ -172,5 +175,6 @@ def check_rc_variation(golden, golden_dir, on_device):
 def test_rhs_cutoff_lists_match_reference_error_table(golden, golden_dir):
     """SURVEY 8(f) N1 goldens: the rhs norms of tests_rhs_rc_variation/*.output, and for every cutoff
     2.0 .. 4.5 the absolute difference of the rhs norms with and without the per-cell atom lists
-    (src/step-50.cc:260-306) as tabulated in Plotting/RHS_Norm_value_comparison_{L2,Linf}.dat."""
+    (src/step-50.cc:260-306) as tabulated in Plotting/RHS_Norm_value_comparison_{L2,Linf}.dat, and of the l2 norm of the per-DoF
+    integrated charge density (Plotting/Total_charge_density_AbsErr_L2.dat)."""
     check_rc_variation(golden, golden_dir, on_device=False)
