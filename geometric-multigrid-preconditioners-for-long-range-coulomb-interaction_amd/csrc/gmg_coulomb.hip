@@ -58,8 +58,9 @@ struct SgsPlan {
   int32_t *stage_ptr = nullptr, *stage_rows = nullptr, *block_row = nullptr, *block_stage = nullptr;
   int n_blocks = 0;
   int n_stages_max = 0;
-  // packed / LDS variant (every block <= kSgsLdsRows rows)
-  bool packed = false;
+  // packed variant: slot-addressed records; y in LDS (every block <= kSgsLdsRows rows) or in global memory
+  bool packed = false, packed_global = false;
+  int32_t *pk_col32 = nullptr;
   int32_t *block_slot = nullptr, *slot_row = nullptr, *block_w = nullptr;
   uint8_t *step_last = nullptr;
   int64_t *block_pk = nullptr;
@@ -670,7 +671,9 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
     p.pk_val = L.sgs.pk_val; p.pk_col = L.sgs.pk_col; p.omega = ctx->omega; p.r = r; p.r_slot = L.sgs.r_slot; p.y = y;
     p.n_slots = L.sgs.n_slots;
     hipLaunchKernelGGL(sgs_gather_rhs_kernel, dim3(grid_for(L.sgs.n_slots)), dim3(kThreads), 0, ctx->stream, p);
-    hipLaunchKernelGGL(sgs_packed_kernel, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
+    p.pk_col32 = L.sgs.pk_col32;
+    if (L.sgs.packed_global) hipLaunchKernelGGL(sgs_packed_kernel<true>, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
+    else hipLaunchKernelGGL(sgs_packed_kernel<false>, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
     return GMG_OK;
   }
   HIPC(hipMemsetAsync(y, 0, sizeof(double) * (size_t)L.n, ctx->stream));
@@ -1048,13 +1051,17 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
   HIPC(hipStreamSynchronize(ctx->stream));
   // ---- packed / LDS variant when every block's y slice fits the LDS
   for (void **p : {(void **)&L.sgs.block_slot, (void **)&L.sgs.slot_row, (void **)&L.sgs.block_w, (void **)&L.sgs.step_last,
-                   (void **)&L.sgs.block_pk, (void **)&L.sgs.pk_val, (void **)&L.sgs.pk_col, (void **)&L.sgs.slot_invd, (void **)&L.sgs.r_slot})
+                   (void **)&L.sgs.block_pk, (void **)&L.sgs.pk_val, (void **)&L.sgs.pk_col, (void **)&L.sgs.pk_col32, (void **)&L.sgs.slot_invd,
+                   (void **)&L.sgs.r_slot})
     if (*p) { (void)hipFree(*p); *p = nullptr; }
-  L.sgs.packed = false;
+  L.sgs.packed = false; L.sgs.packed_global = false;
   int max_rows = 0;
   for (int b = 0; b < n_blocks; ++b) max_rows = std::max(max_rows, block_row[(size_t)b + 1] - block_row[(size_t)b]);
   const char *no_pk = std::getenv("GMG_DISABLE_SGS_PACKED");
-  if (max_rows > 0 && max_rows <= kSgsLdsRows && !(no_pk && no_pk[0] == '1')) {
+  const char *lds_rows_env = std::getenv("GMG_SGS_LDS_ROWS");  // tests: a small value sends small blocks down the global-y variant
+  const int lds_rows = lds_rows_env ? std::atoi(lds_rows_env) : kSgsLdsRows;
+  const bool global_y = max_rows > lds_rows;  // blocks too big for the LDS keep y in global memory (same records, int32 columns)
+  if (max_rows > 0 && !(no_pk && no_pk[0] == '1')) {
     std::vector<int32_t> block_slot((size_t)n_blocks + 1, 0), slot_row, block_w((size_t)n_blocks, 32);
     std::vector<uint8_t> step_last;
     std::vector<int64_t> block_pk((size_t)n_blocks, 0);
@@ -1084,12 +1091,17 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
       block_pk[(size_t)b] = total;
       total += (int64_t)(slot_row.size() - slot0) * block_w[(size_t)b];
       const int n_steps = (int)((slot_row.size() - slot0) / 32);
-      max_lds = std::max(max_lds, (int)(8 * (re - rb) + ((n_steps + 15) / 16) * 16));
+      max_lds = std::max(max_lds, (int)((global_y ? 0 : 8 * (re - rb)) + ((n_steps + 15) / 16) * 16));
     }
     if (max_lds <= 160 * 1024 && total < ((int64_t)1 << 31)) {
       const size_t n_slots = slot_row.size();
       std::vector<double> pk_val((size_t)std::max<int64_t>(total, 1), 0.0);
-      std::vector<uint16_t> pk_col((size_t)std::max<int64_t>(total, 1), 0);
+      std::vector<uint16_t> pk_col(global_y ? 1 : (size_t)std::max<int64_t>(total, 1), 0);
+      std::vector<int32_t> pk_col32(global_y ? (size_t)std::max<int64_t>(total, 1) : 1, 0);
+      auto set_col = [&](int64_t o, int64_t c_local) {
+        if (global_y) pk_col32[(size_t)o] = (int32_t)c_local;
+        else pk_col[(size_t)o] = (uint16_t)c_local;
+      };
       slot_invd.assign(std::max<size_t>(n_slots, 1), 0.0);
       for (int b = 0; b < n_blocks; ++b) {
         const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
@@ -1102,9 +1114,9 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
           double aii = 1.0;
           for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
             if (col[k] == i) aii = val[k];
-            if (col[k] >= rb && col[k] < re) { pk_val[(size_t)(o + c)] = val[k]; pk_col[(size_t)(o + c)] = (uint16_t)(col[k] - rb); ++c; }
+            if (col[k] >= rb && col[k] < re) { pk_val[(size_t)(o + c)] = val[k]; set_col(o + c, col[k] - rb); ++c; }
           }
-          for (; c < w; ++c) { pk_val[(size_t)(o + c)] = 0.0; pk_col[(size_t)(o + c)] = (uint16_t)(i - rb); }
+          for (; c < w; ++c) { pk_val[(size_t)(o + c)] = 0.0; set_col(o + c, i - rb); }
           slot_invd[(size_t)sl] = 1.0 / aii;
         }
       }
@@ -1118,15 +1130,18 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
       SGS_UP(L.sgs.block_pk, block_pk, int64_t)
       SGS_UP(L.sgs.pk_val, pk_val, double)
       SGS_UP(L.sgs.pk_col, pk_col, uint16_t)
+      SGS_UP(L.sgs.pk_col32, pk_col32, int32_t)
       SGS_UP(L.sgs.slot_invd, slot_invd, double)
 #undef SGS_UP
       HIPC(hipMalloc(&L.sgs.r_slot, sizeof(double) * std::max<size_t>(n_slots, 1)));
       HIPC(hipStreamSynchronize(ctx->stream));
       L.sgs.packed = true;
+      L.sgs.packed_global = global_y;
       L.sgs.max_block_rows = max_rows;
       L.sgs.n_slots = (int)n_slots;
       L.sgs.lds_bytes = max_lds;
-      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
   }
   return GMG_OK;
@@ -1150,7 +1165,7 @@ void release_operators(gmg_context *ctx) {
     if (L.copy_l) (void)hipFree(L.copy_l);
     for (void *p : {(void *)L.sgs.stage_ptr, (void *)L.sgs.stage_rows, (void *)L.sgs.block_row, (void *)L.sgs.block_stage,
                     (void *)L.sgs.block_slot, (void *)L.sgs.slot_row, (void *)L.sgs.block_w, (void *)L.sgs.step_last,
-                    (void *)L.sgs.block_pk, (void *)L.sgs.pk_val, (void *)L.sgs.pk_col, (void *)L.sgs.slot_invd, (void *)L.sgs.r_slot})
+                    (void *)L.sgs.block_pk, (void *)L.sgs.pk_val, (void *)L.sgs.pk_col, (void *)L.sgs.pk_col32, (void *)L.sgs.slot_invd, (void *)L.sgs.r_slot})
       if (p) (void)hipFree(p);
     L = Level();
   }

@@ -1097,7 +1097,8 @@ struct SgsPackedArgs {
   const double *slot_invd;    // slot -> 1/a_ii
   const uint8_t *step_last;   // step (= slot / 32) -> 1 if it closes its stage
   const double *pk_val;       // [slot][width of its block]
-  const uint16_t *pk_col;     // local column in the block
+  const uint16_t *pk_col;     // local column in the block (LDS variant)
+  const int32_t *pk_col32;    // the same as int32 (blocks above kSgsLdsRows rows: y stays in global memory)
   double omega;
   const double *r;            // level vector (global row order)
   double *r_slot;             // scratch: r in slot order
@@ -1113,6 +1114,10 @@ __global__ __launch_bounds__(kThreads) void sgs_gather_rhs_kernel(SgsPackedArgs 
   }
 }
 
+// GLOBAL_Y = false: the block's slice of y lives in LDS.  GLOBAL_Y = true (blocks of more than kSgsLdsRows
+// rows): y stays in global memory -- the waves of the one workgroup share the CU's L1, stage ends are a
+// block-scope fence + barrier -- and only the stage-end flags sit in LDS; records and schedule are the same.
+template <bool GLOBAL_Y>
 __global__ __launch_bounds__(1024) void sgs_packed_kernel(SgsPackedArgs a) {
   extern __shared__ double ylds[];
   const int b = blockIdx.x;
@@ -1120,11 +1125,17 @@ __global__ __launch_bounds__(1024) void sgs_packed_kernel(SgsPackedArgs a) {
   const int s0 = a.block_slot[b], n_steps = (a.block_slot[b + 1] - s0) >> 5;
   const int W = a.block_w[b];
   const int64_t pk0 = a.block_pk[b];
-  uint8_t *last = reinterpret_cast<uint8_t *>(ylds + nrows);
+  double *yv = GLOBAL_Y ? a.y + rb : ylds;
+  uint8_t *last = reinterpret_cast<uint8_t *>(GLOBAL_Y ? ylds : ylds + nrows);
   const int hw = threadIdx.x >> 5, hl = threadIdx.x & 31;
-  for (int i = threadIdx.x; i < nrows; i += 1024) ylds[i] = 0.0;
+  for (int i = threadIdx.x; i < nrows; i += 1024) yv[i] = 0.0;
   for (int i = threadIdx.x; i < n_steps; i += 1024) last[i] = a.step_last[(s0 >> 5) + i];
+  if constexpr (GLOBAL_Y) __threadfence_block();
   __syncthreads();
+  auto col_at = [&](int64_t o) -> int {
+    if constexpr (GLOBAL_Y) return a.pk_col32[o];
+    else return a.pk_col[o];
+  };
   for (int dir = 0; dir < 2; ++dir) {
     // forward: steps 0 .. n-1; backward: n-1 .. 0 (stages in reverse order; the steps of one stage
     // are mutually independent, so their order inside the stage does not matter)
@@ -1137,7 +1148,7 @@ __global__ __launch_bounds__(1024) void sgs_packed_kernel(SgsPackedArgs a) {
       prow = a.slot_row[slot];
       const int64_t o = pk0 + (int64_t)(slot - s0) * W + hl;
       pv = a.pk_val[o];
-      pc = a.pk_col[o];
+      pc = col_at(o);
       pr = a.r_slot[slot];
       pinv = a.slot_invd[slot];
     };
@@ -1149,23 +1160,28 @@ __global__ __launch_bounds__(1024) void sgs_packed_kernel(SgsPackedArgs a) {
       prefetch(t + dt);
       if (crow >= 0) {
         double acc = 0.0;
-        double prod = cv * ylds[cc];
+        double prod = cv * yv[cc];
 #pragma unroll
         for (int k = 0; k < 32; ++k) acc += __shfl(prod, k, 32);
         for (int kb = 32; kb < W; kb += 32) {  // rows wider than 32 in-block entries (rare)
           const int64_t o = pk0 + (int64_t)((t << 5) + hw) * W + kb + hl;
-          prod = a.pk_val[o] * ylds[a.pk_col[o]];
+          prod = a.pk_val[o] * yv[col_at(o)];
 #pragma unroll
           for (int k = 0; k < 32; ++k) acc += __shfl(prod, k, 32);
         }
-        if (hl == 0) ylds[crow - rb] += a.omega * (cr - acc) * cinv;
+        if (hl == 0) yv[crow - rb] += a.omega * (cr - acc) * cinv;
       }
       const bool end_stage = dir == 0 ? last[t] != 0 : (t == 0 || last[t - 1] != 0);
-      if (end_stage) __syncthreads();
+      if (end_stage) {
+        if constexpr (GLOBAL_Y) __threadfence_block();
+        __syncthreads();
+      }
     }
+    if constexpr (GLOBAL_Y) __threadfence_block();
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < nrows; i += 1024) a.y[rb + i] = ylds[i];
+  if constexpr (!GLOBAL_Y)
+    for (int i = threadIdx.x; i < nrows; i += 1024) a.y[rb + i] = ylds[i];
 }
 
 }  // namespace gmg

@@ -237,11 +237,14 @@ def test_single_rank_communicator_path(hier45):
     c.close()
 
 
-@pytest.mark.parametrize("blocks,packed", [(3, True), (16, True), (1, False), (3, False)])
-def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, packed, monkeypatch):
-    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks); with and
-    without the LDS-resident variant (blocks of more than 16 k rows sweep through global memory)."""
-    if not packed:
+@pytest.mark.parametrize("blocks,variant", [(3, "lds"), (16, "lds"), (1, "global"), (3, "global"), (1, "sweep"), (3, "sweep")])
+def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant, monkeypatch):
+    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the three
+    device variants: slot-addressed records with y in LDS (blocks up to 16 k rows), the same records with y
+    in global memory (bigger blocks; forced here by GMG_SGS_LDS_ROWS), and the plain CSR sweep."""
+    if variant == "global":
+        monkeypatch.setenv("GMG_SGS_LDS_ROWS", "100")
+    if variant == "sweep":
         monkeypatch.setenv("GMG_DISABLE_SGS_PACKED", "1")
     level = 4
     n = hier3.level_matrices[level].n_rows
