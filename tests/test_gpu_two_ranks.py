@@ -64,11 +64,12 @@ def test_six_adaptive_cycles_on_several_ranks(golden, golden_dir, tmp_path, monk
                 assert rel_close(a[k], b[k], 13), k
 
 
-def test_three_kernel_coarse_cg_on_two_ranks(golden_dir, tmp_path, monkeypatch):
+def test_three_kernel_coarse_cg_on_two_and_three_ranks(golden_dir, tmp_path, monkeypatch):
     """BASELINE config 2 (8 atoms, 45^3 level 0, Jacobi smoother) on two ranks against the same problem
     in the single-GPU layout: distributed three-kernel coarse CG (direction ring + x flush, halo of d,
     all-reduced dot products), two adaptive cycles."""
     two = run_ranks(2, golden_dir, tmp_path, monkeypatch, nacl=1)
+    two += run_ranks(3, golden_dir, tmp_path, monkeypatch, nacl=1)  # unequal chunks, a middle rank with two neighbours
     one = run_ranks(0, golden_dir, tmp_path, monkeypatch, nacl=1)[0]
     # "Partition level 0 = auto": a 45^3 level 0 stays replicated (every rank runs the single-GPU coarse CG),
     # the system matrix and the outer CG vectors are still partitioned
