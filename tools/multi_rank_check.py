@@ -1,5 +1,5 @@
 """Runs an NaCl workload (cells per side) on 2 and 3 ranks sharing one GPU (shared-memory transport) and compares every
-cycle with the single-GPU layout: python tools/multi_rank_check.py 5"""
+cycle with the single-GPU layout: python tools/multi_rank_check.py 5 [ranks:always|auto ...]  (at most 6 GPU processes per box)"""
 import os, sys, json, subprocess, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,7 +19,8 @@ def run(n_ranks, nacl, part):
     return [json.load(open(o)) for o in outs]
 nacl = int(sys.argv[1])
 one = run(0, nacl, "auto")[0]
-for n, part in ((2, "always"), (3, "always"), (2, "auto")):
+configs = [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[2:]] or [(2, "always"), (3, "always"), (2, "auto")]
+for n, part in configs:
     reps = run(n, nacl, part)
     for rk, rep in enumerate(reps):
         for c, (r, g) in enumerate(zip(rep, one)):
