@@ -6,12 +6,18 @@ to 1e-8 |b| with one V-cycle per iteration) on the operators of one adaptive cyc
 cycle's initial guess, with every operator and vector already resident in HBM.  value =
 (active DoFs x outer CG iterations) / time per step, summed over what all ranks solve.
 
+The headline uses the reference's smoother: SSOR(0.5) x 2 steps (src/step-50.cc:970-973), swept
+exactly as one rank of the reference sweeps it (--ssor-blocks 1).  The same operators are then
+solved with the reference's smoother as 20 ranks apply it (block SSOR, the cluster runs), with
+Jacobi and with Chebyshev: `config.smoothers`.
+
   python bench.py --gpus 1 --steps 5 --warmup 2 [--workload atoms64000|atoms8000|atoms1000|atoms8|stress201]
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,21 +35,39 @@ WORKLOADS = {
     "stress201": dict(nacl=40, box=40.0, label="3D NaCl 512k atoms (same generator), 201^3 level 0"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# context only (different hardware, 5 cycles incl. build_matrices): BASELINE.md section 1
+# context only (different hardware: 20 CPU ranks, SSOR smoother, 5 cycles incl. build_matrices): BASELINE.md section 1
 REFERENCE_SOLVE = {"atoms8": 2.40e6, "atoms1000": 2.06e6, "atoms8000": 1.81e6, "atoms64000": 2.31e6}
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json, produced by
-    tools/gpu_pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, corrected as
-    MI355X_MICROARCH.md prescribes); None when no pass exists for this kernel."""
+def git_head():
+    """Commit of the tree being measured: from git, or (on a GPU box, where .git does not travel) from the stamp
+    tools/stamp_commit.sh leaves in .bench_commit."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        try:
+            with open(os.path.join(ROOT, ".bench_commit")) as fh:
+                return fh.read().strip() or None
+        except OSError:
+            return None
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/gpu_pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, corrected as
+    MI355X_MICROARCH.md prescribes).  A LOOKUP of an earlier run, not a measurement of this one: returns
+    (bytes, provenance) or (None, reason) when no pass exists for exactly this kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
             d = json.load(fh)
-        e = d.get(workload, {}).get(kernel)
-        return e["traffic_bytes"] if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+        w = d.get(workload, {})
+        e = w.get("kernels", w).get(kernel)
+        if not e:
+            return None, f"no PMC pass for {kernel} on {workload} in profiles/pmc_traffic.json"
+        return e["traffic_bytes"], f"lookup: profiles/pmc_traffic.json ({w.get('commit', 'commit not recorded')}; {e.get('launches', '?')} launches)"
+    except (OSError, ValueError, KeyError) as exc:
+        return None, f"profiles/pmc_traffic.json unreadable: {exc}"
 
 
 def spmv_bytes(n, nnz):  # SURVEY.md 8(d)
@@ -56,7 +80,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="atoms64000", choices=sorted(WORKLOADS))
-    ap.add_argument("--smoother", default="Jacobi", choices=["Jacobi", "SSOR", "Chebyshev"])
+    ap.add_argument("--smoother", default="SSOR", choices=["Jacobi", "SSOR", "Chebyshev"],
+                    help="smoother of the headline solve (default: the reference's, src/step-50.cc:970)")
+    ap.add_argument("--ssor-blocks", type=int, default=1,
+                    help="SSOR as the reference applies it on this many MPI ranks (1 = exact sequential sweep)")
+    ap.add_argument("--no-smoother-table", action="store_true", help="skip the solves with the other smoothers (config.smoothers)")
     ap.add_argument("--cycles", type=int, default=5, help="adaptive cycles to run (the reference runs 5); the last one is timed")
     ap.add_argument("--partition-level0", default="auto", choices=["auto", "always", "never"],
                     help="N > 1: row-partition level 0 (coarse CG over RCCL) or keep it replicated; auto decides by size (DESIGN.md 6)")
@@ -99,7 +127,8 @@ def main():
     S.set_threads(max(1, min(16, (os.cpu_count() or 16) // max(1, world))))
     p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
-                             quad_rhs=1, global_refinement=0, smoother=args.smoother, partition_level0=args.partition_level0))
+                             quad_rhs=1, global_refinement=0, smoother=args.smoother, ssor_blocks=args.ssor_blocks,
+                             partition_level0=args.partition_level0))
     p.set_nacl_atoms(w["nacl"])
     if launched:
         # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
@@ -117,27 +146,57 @@ def main():
     t_setup = time.time() - t_setup
     ctx = pkg.capi.Context.view(p.gmg_context())  # non-owning view of the problem's gmg_context (stats)
 
-    for _ in range(args.warmup):
-        p.solve_again()
-    ctx.set_profiling(args.profile_every)
-    ctx.stats_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rep_t = p.solve_again()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_profiling(0)
+    def timed_solves(steps, warmup, profile_every):
+        """`steps` passes of the hot path between barriers; returns (seconds, last report, stats of the timed region)."""
+        for _ in range(warmup):
+            p.solve_again()
+        ctx.set_profiling(profile_every)
+        ctx.stats_reset()
+        barrier()
+        t0 = time.perf_counter()
+        r = None
+        for _ in range(steps):
+            r = p.solve_again()
+        barrier()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        ctx.set_profiling(0)
+        if launched:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, r, st
+
+    dt, rep_t, st = timed_solves(args.steps, args.warmup, args.profile_every)
     hbm_read, hbm_copy = ctx.calibrate_hbm(1 << 30, 10) if rank == 0 else (0.0, 0.0)
-    if launched:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     ms_per_step = dt / args.steps * 1e3
     dofs, its = rep["dofs"], rep_t["cg_iterations"]
     value = dofs * its / (dt / args.steps)  # the ranks solve ONE problem together (strong scaling)
+
+    def smoother_entry(name, blocks, dt_, steps_, r_, st_):
+        e = {"smoother": name, "ms_per_solve": round(dt_ / steps_ * 1e3, 3), "outer_cg_iterations": r_["cg_iterations"],
+             "coarse_cg_iterations": int(r_["coarse_iterations"]), "DoF_it_per_s": dofs * r_["cg_iterations"] / (dt_ / steps_)}
+        if name == "SSOR":
+            e["ssor_blocks"] = blocks
+            e["sweep"] = "exact sequential order (the reference on 1 rank)" if blocks == 1 else f"block Jacobi of rank-local sweeps (the reference on {blocks} ranks)"
+            if st_.sgs_samples:
+                e["sweep_launches_per_solve"] = round(st_.sgs_samples / steps_, 1)
+                e["sweep_ms_per_solve"] = round(st_.sgs_ms_total / steps_, 3)
+                e["sweep_ns_per_dependent_substep"] = round(st_.sgs_ms_total * 1e6 / max(1, st_.sgs_substeps) * (blocks if blocks > 1 else 1), 1)
+        return e
+
+    head_key = f"SSOR_B{args.ssor_blocks}" if args.smoother == "SSOR" else args.smoother
+    smoothers = {head_key: smoother_entry(args.smoother, args.ssor_blocks, dt, args.steps, rep_t, st)}
+    if not args.no_smoother_table and world == 1:
+        for name, blocks in (("SSOR", 1), ("SSOR", 20), ("Jacobi", 1), ("Chebyshev", 1)):
+            key = f"SSOR_B{blocks}" if name == "SSOR" else name
+            if key in smoothers:
+                continue
+            p.set_smoother(name, blocks)
+            dt2, r2, st2 = timed_solves(3, 1, 1)
+            smoothers[key] = smoother_entry(name, blocks, dt2, 3, r2, st2)
+        p.set_smoother(args.smoother, args.ssor_blocks)
 
     n0, nnz0 = st.spmv0_rows, st.spmv0_nnz
     roof = None
@@ -150,27 +209,31 @@ def main():
         # unfused variant (large level 0): plain SpMV + partial d.h
         fused = st.coarse_variant == 1
         alg = spmv_bytes(n0, nnz0) + (16 * n0 if fused else 0)
-        ach = alg / t_k / 1e9
         lay = int(st.spmv0_layout)
         val8, col16 = bool(lay >= 1 and (lay - 1) & 2), bool(lay >= 1 and (lay - 1) & 4)
         tmpl = f"0, {1 if fused else 2}" + (f", {'true' if val8 else 'false'}, {'true' if col16 else 'false'}" if lay >= 1 else "")
         kname = ("spmv_sell_kernel" if lay >= 1 else "spmv_tile_kernel") + f"<{tmpl}>"
         if lay >= 1 and (lay - 1) & 8:  # lattice operator: pattern-run kernel (pair loads + lane shift)
             kname = f"spmv_sellp_kernel<0, {1 if fused else 2}>"
-        # bytes the internal layout actually streams: SELL-64 pads rows to a multiple of 4 entries;
-        # values are 1-byte dictionary codes (val8) or fp64, columns 2-byte offsets (col16) or int32
-        # (pattern slices stream no columns at all); the library reports the exact size of those streams
+        # bytes the kernel actually moves: the operator in its device layout (SELL-64, 1-byte value codes, column
+        # patterns: the library reports the exact size of the streams) + x read + y written (+ g, d when fused)
         moved = int(st.spmv0_matrix_bytes) + 16 * n0 + (16 * n0 if fused else 8 * n0)
+        traffic, traffic_src = pmc_traffic(args.workload, kname)
+        ach = moved / t_k / 1e9
         roof = {"bound": "hbm", "kernel": kname + (" (level-0 SpMV + CG direction update)" if fused else " (level-0 SpMV + d.h partials)"),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(args.workload, kname), "bytes_per_launch": alg,
-                "note": "achieved = ALGORITHMIC CSR bytes (12 nnz + 4 (N+1) + 16 N [+16 N fused]) / launch time; the kernel "
-                        "streams a compressed SELL-64 copy (layout_bytes_per_launch; traffic = PMC-measured HBM bytes), so "
-                        "achieved may exceed the HBM peak; achieved_layout = bytes of that layout / time is the figure "
-                        "bounded by the 8 TB/s roofline (the compressed kernels are bound by vector-load issue and VALU work per "
-                        "slice, not by HBM: DESIGN.md section 3)",
-                "layout_bytes_per_launch": int(moved), "pattern_slices": [int(st.spmv0_pattern_slices), int(st.spmv0_slices)], "achieved_layout": round(moved / t_k / 1e9, 1),
-                "frac_layout": round(moved / t_k / 1e9 / HBM_PEAK_GBS, 4), "measured_stream_read_GBps": round(hbm_read, 1),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": int(moved),
+                "note": "achieved = bytes the kernel moves per launch in its device layout (the operator as compressed "
+                        "SELL-64 streams + the vectors) / the launch's own duration (HIP events on the dispatch); "
+                        "`traffic` is the PMC figure for the same kernel from a separate profiling run.  The caller hands over "
+                        "CSR: against SURVEY 8(d)'s algorithmic CSR bytes the same launch is `effective_vs_csr`.  At 121^3 one "
+                        "coarse iteration's working set fits the 256 MiB Infinity Cache, so `achieved` is a cache-assisted rate; "
+                        "the stress201 workload (beyond the cache) is the HBM-resident figure (DESIGN.md section 5)",
+                "effective_vs_csr": {"algorithmic_bytes_per_launch": alg, "GB_per_s": round(alg / t_k / 1e9, 1),
+                                     "x_peak": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 3)},
+                "pattern_slices": [int(st.spmv0_pattern_slices), int(st.spmv0_slices)],
+                "measured_stream_read_GBps": round(hbm_read, 1),
                 "measured_stream_copy_GBps": round(hbm_copy, 1), "avg_launch_us": round(t_k * 1e6, 2),
                 "launches_sampled": int(st.spmv0_samples), "noop_launches_sampled": int(st.spmv0_noop_samples),
                 "avg_noop_launch_us": None if t_noop is None else round(t_noop * 1e6, 2),
@@ -184,10 +247,21 @@ def main():
             upd_name, upd_bytes = ("cg_update_kernel", 48 * n0) if fused else ("cg_update_g_kernel", 24 * n0)
             roof[upd_name] = {"avg_launch_us": round(t_u * 1e6, 2), "bytes_per_launch": upd_bytes,
                               "achieved": round(upd_bytes / t_u / 1e9, 1)}
+        # one whole coarse-CG iteration (SpMV + direction + g update + 1/8 x flush), timed on a level-0 solve of its own
+        if world == 1:
+            roof["coarse_iteration"] = coarse_iteration_rate(ctx, int(n0), moved, fused)
+        if st.sgs_samples:
+            roof["kernel_time_per_step"] = {
+                "level0_spmv_ms": round(t_k * 1e3 * st.coarse_iterations / args.steps, 3),
+                "ssor_sweep_ms": round(st.sgs_ms_total / args.steps, 3),
+                "ssor_sweep_note": "sgs_wave_kernel is a chain of dependent sub-steps (one wave, y in LDS): latency bound, "
+                                   "no bandwidth roofline applies; its figure of merit is ns per dependent sub-step",
+                "ssor_sweep_ns_per_dependent_substep": smoothers[head_key].get("sweep_ns_per_dependent_substep"),
+                "ssor_sweep_stream_GBps": round(st.sgs_stream_bytes / max(1e-9, st.sgs_ms_total * 1e-3) / 1e9, 2)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(p, rep, args.smoother)
+        cpu = cpu_baseline(p, rep, args.smoother, args.ssor_blocks)
 
     if rank == 0:
         out = {
@@ -195,13 +269,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["label"] + f", adaptive cycle {args.cycles - 1} of {args.cycles}", "cycle": args.cycles - 1,
-                       "smoother": args.smoother, "cycles": cycles,
+                       "smoother": args.smoother + (f" (0.5, 2 steps), {args.ssor_blocks} block(s)" if args.smoother == "SSOR" else ""),
+                       "smoothers": smoothers, "cycles": cycles,
                        "all_cycles_DoF_it_per_s": sum(c["dofs"] * c["outer_cg_iterations"] for c in cycles)
                        / max(1e-12, sum(c["solve_ms"] for c in cycles) * 1e-3),
-                       "reference_cpu_20_ranks_DoF_it_per_s": REFERENCE_SOLVE.get(args.workload),
+                       "reference_cpu_20_ranks_SSOR_DoF_it_per_s": REFERENCE_SOLVE.get(args.workload),
                        "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
                        "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
                        "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),
+                       "rccl_ranks": world if launched else 0, "commit": git_head(),
                        "parallelism": f"{world} rank(s), one per GPU" + ("" if world == 1 else (
                            "; system matrix + outer CG rows partitioned, level 0 " +
                            ("partitioned (halo exchange + 2 all-reduces per coarse iteration over RCCL)" if int(n0) < rep["dofs_by_level"][0]
@@ -216,7 +292,34 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(p, rep, smoother):
+def coarse_iteration_rate(ctx, n0, spmv_moved, fused):
+    """Bytes moved by one whole coarse-CG iteration / its duration, from a level-0 solve of its own (MGCoarseGrid
+    operator() on a fixed right-hand side, timed on the host around the device-resident iteration loop)."""
+    import numpy as np
+
+    b = np.zeros(n0)
+    b[n0 // 2] = 1.0
+    vb, vx = ctx.vector(n0, b), ctx.vector(n0)
+    ctx.coarse_solve(vx, vb)
+    t0 = time.perf_counter()
+    reps, its = 3, 0
+    for _ in range(reps):
+        it, _, _ = ctx.coarse_solve(vx, vb)
+        its += it
+    dt = time.perf_counter() - t0
+    vb.free()
+    vx.free()
+    if its == 0:
+        return None
+    # fused: SpMV(+direction) + update (48 N); three-kernel: SpMV + direction (24 N) + g update (24 N) + x flush (80 N / 8)
+    moved = spmv_moved + (48 * n0 if fused else 24 * n0 + 24 * n0 + 10 * n0)
+    us = dt / its * 1e6
+    return {"us_per_iteration": round(us, 2), "bytes_moved": int(moved), "achieved": round(moved / us / 1e3, 1), "unit": "GB/s",
+            "frac": round(moved / us / 1e3 / HBM_PEAK_GBS, 4), "iterations_timed": int(its),
+            "note": "includes kernel boundaries and the host's convergence polls"}
+
+
+def cpu_baseline(p, rep, smoother, ssor_blocks):
     """The oracle (CPU restatement, kind 'port') timed on this box's host cores on the same
     operators: one full solve of the timed cycle when it fits ~30 s, else a bounded number of
     level-0 CG iterations scaled up."""
@@ -233,11 +336,11 @@ def cpu_baseline(p, rep, smoother):
     full = rep["coarse_iterations"] <= budget_its
     t0 = time.perf_counter()
     if full:
-        mg = go.OracleMG(h, smoother=kind)
+        mg = go.OracleMG(h, smoother=kind, ssor_blocks=ssor_blocks)
         r = mg.solve(h.system_rhs, x0=p.vector("initial_guess"))
         dt = time.perf_counter() - t0
         value = rep["dofs"] * r["iterations"] / dt
-        sample = f"one full solve of the timed cycle: {r['iterations']} outer / {r['coarse_iterations']} coarse CG iterations, {dt:.2f} s"
+        sample = f"one full solve of the timed cycle ({smoother} smoother): {r['iterations']} outer / {r['coarse_iterations']} coarse CG iterations, {dt:.2f} s"
     else:
         mg = go.OracleMG(h, smoother=kind, coarse_maxit=budget_its)
         mg.coarse_solve(h.system_rhs if len(h.level_matrices) == 1 else h.system_rhs[:n0] * 0 + 1.0)

@@ -29,7 +29,7 @@ SYMBOLS = [
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
     "gmg_comm_unique_id", "gmg_comm_init", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
     "gmg_vec_allgather",
-    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density",
+    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_option", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density",
 ]
 
 
@@ -39,7 +39,8 @@ class Stats(C.Structure):
                 ("spmv0_nnz", C.c_int64), ("cgupd_samples", C.c_int64), ("cgupd_ms_total", C.c_double),
                 ("coarse_variant", C.c_int64), ("spmv0_layout", C.c_int64), ("spmv0_matrix_bytes", C.c_int64),
                 ("spmv0_pattern_slices", C.c_int64), ("spmv0_slices", C.c_int64), ("coarse_enqueued", C.c_int64),
-                ("spmv0_noop_samples", C.c_int64), ("spmv0_noop_ms_total", C.c_double)]
+                ("spmv0_noop_samples", C.c_int64), ("spmv0_noop_ms_total", C.c_double),
+                ("sgs_samples", C.c_int64), ("sgs_ms_total", C.c_double), ("sgs_substeps", C.c_int64), ("sgs_stream_bytes", C.c_int64)]
 
 
 class GMGError(RuntimeError):
@@ -297,3 +298,7 @@ class Context:
         self._chk(self.L.gmg_set_tuning(self.h, C.c_int(coarse_chunk), C.c_int(cg_variant)))
         if ssor_blocks:
             self._chk(self.L.gmg_set_ssor_blocks(self.h, C.c_int(ssor_blocks)))
+
+    def set_option(self, key: str, value: float = 1.0):
+        """Diagnostic / measurement options by name (include/gmg_coulomb.h: gmg_set_option)."""
+        self._chk(self.L.gmg_set_option(self.h, key.encode(), C.c_double(value)))

@@ -8,6 +8,7 @@
 // :938-1017 as restated in SURVEY.md 3.2.
 #include "../../include/gmg_coulomb.h"
 #include "gmg_device.hpp"
+#include "gmg_sgs.hpp"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -55,18 +56,18 @@ struct DevCSR {
 };
 
 struct SgsPlan {
+  // generic level-scheduled sweep straight from the CSR copy (fallback: rows with unsorted columns)
   int32_t *stage_ptr = nullptr, *stage_rows = nullptr, *block_row = nullptr, *block_stage = nullptr;
   int n_blocks = 0;
   int n_stages_max = 0;
-  // packed variant: slot-addressed records; y in LDS (every block <= kSgsLdsRows rows) or in global memory
-  bool packed = false, packed_global = false;
-  int32_t *pk_col32 = nullptr;
-  int32_t *block_slot = nullptr, *slot_row = nullptr, *block_w = nullptr;
-  uint8_t *step_last = nullptr;
-  int64_t *block_pk = nullptr;
-  double *pk_val = nullptr, *slot_invd = nullptr, *r_slot = nullptr;
-  uint16_t *pk_col = nullptr;
-  int max_block_rows = 0, n_slots = 0, lds_bytes = 0;
+  // wavefront sweep with y in LDS (gmg_sgs.hpp)
+  bool wave = false;
+  SwRange *w_ranges = nullptr;
+  int32_t *w_block_rng = nullptr, *w_ws_ci = nullptr, *w_ci_row = nullptr, *w_row_ci = nullptr, *w_rpos_f = nullptr, *w_rpos_b = nullptr;
+  char *w_stream = nullptr;
+  double *w_ycur = nullptr, *w_iso_diag = nullptr, *w_iso_invd = nullptr;
+  int w_y_slots = 0, w_lds_bytes = 0, w_n_ranges = 0;
+  int64_t w_n_coupled = 0, w_stream_bytes = 0, w_steps = 0, w_stages = 0;
 };
 
 struct Level {
@@ -117,13 +118,21 @@ struct gmg_context {
   double *scal_host = nullptr;                  // pinned, 8 doubles
   // tuning / measurement
   int coarse_chunk = 0;
+  // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
+  int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
+  bool sgs_disable_wave = false, debug_upload = false, sgs_profile = false;
+  int sgs_profile_mode = 0;
+  bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false;
+  int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
+  double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
   int ssor_blocks = 1;  // 1 = exact sequential SGS; B > 1 = block Jacobi of SGS (the reference on B ranks)
   int cg_variant = 0;  // 0 auto, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration
   int last_coarse_iters = 0;
   int prof_every = 0;
   std::vector<hipEvent_t> ev_a, ev_b;  // sampled level-0 SpMV launches
   std::vector<hipEvent_t> ev_c, ev_d;  // sampled update-kernel launches
-  int ev_used = 0, ev2_used = 0;
+  std::vector<hipEvent_t> ev_e, ev_f;  // SSOR sweep launches
+  int ev_used = 0, ev2_used = 0, ev3_used = 0;
   hipEvent_t timed_start = nullptr, timed_stop = nullptr;  // next launch carries these as its dispatch start / stop events
   gmg_stats stats{};
   Comm comm;
@@ -197,13 +206,10 @@ void free_csr(DevCSR &m) {
 
 // Host CSR -> device CSR + LDS-window tiling.
 // Host-side setup loops (layout conversion of 10^7..10^8 nonzeros) run on a few threads: f(begin, end, chunk)
+int g_host_threads = 0;  // option "host_threads" (process-wide); 0 = hardware concurrency, at most 16
 inline int host_threads() {
-  static const int n = [] {
-    const char *e = std::getenv("GMG_HOST_THREADS");
-    int t = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
-    return std::max(1, std::min(16, t));
-  }();
-  return n;
+  const int t = g_host_threads > 0 ? g_host_threads : (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(16, t));
 }
 template <class F>
 void parallel_chunks(int64_t n, F f) {
@@ -229,7 +235,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   free_csr(m);
   m.halo = keep;
   m.n_rows = n_rows; m.n_cols = n_cols; m.nnz = nnz;
-  static const bool dbg_upload = std::getenv("GMG_DEBUG_UPLOAD") != nullptr;
+  const bool dbg_upload = ctx->debug_upload;
   auto t_phase = std::chrono::steady_clock::now();
   auto phase = [&](const char *what) {
     if (!dbg_upload) return;
@@ -279,17 +285,13 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   m.valid = true;
   phase("csr copy");
   // SELL-64 copy when the rows are regular enough (level-0 lattice, active-mesh matrix)
-  const char *no_sell = std::getenv("GMG_DISABLE_SELL");
-  if (n_rows >= 1024 && !(no_sell && no_sell[0] == '1')) {
+  if (n_rows >= 1024 && !ctx->disable_sell) {
     const int64_t n_slices = (n_rows + 63) / 64;
-    const char *dbg = std::getenv("GMG_DEBUG_NOGATHER");  // timing experiments only: every column -> own row
-    const bool debug_nogather = dbg && dbg[0] == '1';
     std::vector<int32_t> sp((size_t)n_slices + 1, 0);
     // column patterns: a slice qualifies when all 64 rows exist and the union of (col - row) over
     // its rows has <= 32 members that are valid columns for every row; rows lacking a member get an
     // explicit +0.0 there (exact: x is finite), which keeps the CSR summation order
-    const char *no_pat = std::getenv("GMG_DISABLE_PATTERNS");
-    const bool allow_pat = !(no_pat && no_pat[0] == '1') && n_rows == n_cols;
+    const bool allow_pat = !ctx->disable_patterns && n_rows == n_cols;
     std::vector<int32_t> spat((size_t)n_slices, -1);
     std::vector<std::vector<int32_t>> patterns;
     std::map<std::vector<int32_t>, int> pattern_id;
@@ -333,8 +335,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
     if (quads * 256 <= (int64_t)(1.12 * (double)nnz) && quads * 256 < ((int64_t)1 << 31)) {
       phase("patterns");
       // --- value dictionary (bit patterns, so -0.0 / NaN payloads survive)
-      const char *no_comp = std::getenv("GMG_DISABLE_COMPRESSION");
-      const bool allow_comp = !(no_comp && no_comp[0] == '1');
+      const bool allow_comp = !ctx->disable_compression;
       std::vector<double> dict;
       std::unordered_map<uint64_t, int> code_of;
       bool val8 = allow_comp;
@@ -433,7 +434,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
               if (j < (int64_t)dl.size() && kk < len && col[k0 + kk] - r2 == dl[(size_t)j]) { cj = col[k0 + kk]; vj = val[k0 + kk]; ++kk; }
               else { cj = (int32_t)(j < (int64_t)dl.size() ? r2 + dl[(size_t)j] : r2); vj = 0.0; }
             } else {
-              cj = (j < len && !debug_nogather) ? col[k0 + j] : padcol;
+              cj = j < len ? col[k0 + j] : padcol;
               vj = j < len ? val[k0 + j] : 0.0;
             }
             if (val8) { uint64_t bits; std::memcpy(&bits, &vj, 8); v1[oc] = code_lookup(bits); }
@@ -485,9 +486,8 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
           m.sellp_pid = (int)pi;
           for (size_t u = 0; u < 9; ++u) m.sellp_centre[u] = dl[3 * u + 1];
         }
-        const char *no_p = std::getenv("GMG_DISABLE_SELLP");
         // a streamed slice costs ~4 pattern slices here against ~2.2 in the per-entry kernel: worth it up to ~40 % streamed slices
-        m.use_sellp = val8 && !(no_p && no_p[0] == '1') && n_run_slices * 10 >= n_slices * 7;
+        m.use_sellp = val8 && !ctx->disable_sellp && n_run_slices * 10 >= n_slices * 7;
       }
       m.sell = true;
       m.n_slices = (int)n_slices;
@@ -496,14 +496,13 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
       // one wave per >= 1 slice; at most kMaxPartials workgroups (one reduction partial each)
       const int per_xcd = (int)((n_slices + 7) / 8);
       m.sell_grid = 8 * std::min(kMaxPartials / 8, std::max(1, (per_xcd + 3) / 4));
-      if (const char *g = std::getenv("GMG_SELL_GRID")) m.sell_grid = std::max(8, std::atoi(g) / 8 * 8);
+      if (ctx->sell_grid > 0) m.sell_grid = std::max(8, ctx->sell_grid / 8 * 8);
       if (m.use_sellp) {
         // as many workgroups as are resident at the kernel's register budget: one round
-        if (!std::getenv("GMG_SELL_GRID")) m.sell_grid = std::min(m.sell_grid, 256 * kSellpWaves);
+        if (ctx->sell_grid <= 0) m.sell_grid = std::min(m.sell_grid, 256 * kSellpWaves);
         // contiguous slice ranges per wave, balanced by cost: a streamed slice (one memory round trip
         // per quad) costs about four pattern slices
-        double other_cost = 4.0;
-        if (const char *c = std::getenv("GMG_SELLP_COST")) other_cost = std::atof(c);
+        const double other_cost = ctx->sellp_cost;
         const int n_waves = m.sell_grid * 4;
         std::vector<double> cost(n_slices + 1, 0.0);
         for (size_t sl = 0; sl < n_slices; ++sl)
@@ -532,7 +531,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
     }
   }
   phase("finish");
-  if (std::getenv("GMG_DEBUG_UPLOAD"))
+  if (ctx->debug_upload)
     std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d patterns %d pattern_slices %d/%d\n", (long long)n_rows,
                  (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid, m.n_patterns, m.n_pattern_slices, m.n_slices);
   return GMG_OK;
@@ -663,17 +662,59 @@ int dot_host(gmg_context *ctx, const double *x, const double *y, int64_t n, doub
 
 // ---- smoothers (A7) ---------------------------------------------------------------------
 
+// event times of the SSOR sweep launches bracketed so far -> stats (waits for the stream)
+void collect_sgs_samples(gmg_context *ctx) {
+  if (ctx->ev3_used == 0) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < ctx->ev3_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_e[(size_t)i], ctx->ev_f[(size_t)i]) != hipSuccess) continue;
+    ctx->stats.sgs_ms_total += ms;
+    ctx->stats.sgs_samples++;
+  }
+  ctx->ev3_used = 0;
+}
+
+// option sgs_profile: the instrumented variant of the sweep; prints where each range of the first blocks spent its cycles
+int sgs_profile_launch(gmg_context *ctx, Level &L, SgsWaveArgs p) {
+  const size_t nr = (size_t)L.sgs.w_n_ranges;
+  unsigned long long *d = nullptr;
+  std::vector<unsigned long long> h(4 * nr, 0);
+  HIPC(hipMalloc(&d, sizeof(unsigned long long) * 4 * nr));
+  p.prof = d;
+  p.prof_mode = ctx->sgs_profile_mode;
+  hipLaunchKernelGGL(sgs_wave_kernel<true>, dim3(L.sgs.n_blocks), dim3(kSwThreads), (size_t)L.sgs.w_lds_bytes, ctx->stream, p);
+  HIPC(hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 4 * nr, hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d);
+  if (L.sgs.w_steps > 1000) {
+    std::fprintf(stderr, "[gmg] SGS sweep profile mode %d (%lld rows, %d ranges; shader cycles: sweep / of it waiting for the ring / load / write-back):", ctx->sgs_profile_mode, (long long)L.n, (int)nr);
+    for (size_t i = 0; i < std::min<size_t>(nr, 10); ++i)
+      std::fprintf(stderr, " [%llu %llu %llu %llu]", h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+    std::fprintf(stderr, "\n");
+  }
+  return GMG_OK;
+}
+
 int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
-  if (L.sgs.packed) {
-    SgsPackedArgs p{};
-    p.block_row = L.sgs.block_row; p.block_slot = L.sgs.block_slot; p.block_pk = L.sgs.block_pk; p.block_w = L.sgs.block_w;
-    p.slot_row = L.sgs.slot_row; p.slot_invd = L.sgs.slot_invd; p.step_last = L.sgs.step_last;
-    p.pk_val = L.sgs.pk_val; p.pk_col = L.sgs.pk_col; p.omega = ctx->omega; p.r = r; p.r_slot = L.sgs.r_slot; p.y = y;
-    p.n_slots = L.sgs.n_slots;
-    hipLaunchKernelGGL(sgs_gather_rhs_kernel, dim3(grid_for(L.sgs.n_slots)), dim3(kThreads), 0, ctx->stream, p);
-    p.pk_col32 = L.sgs.pk_col32;
-    if (L.sgs.packed_global) hipLaunchKernelGGL(sgs_packed_kernel<true>, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
-    else hipLaunchKernelGGL(sgs_packed_kernel<false>, dim3(L.sgs.n_blocks), dim3(1024), (size_t)L.sgs.lds_bytes, ctx->stream, p);
+  if (L.sgs.wave) {
+    SgsWaveArgs p{};
+    p.ranges = L.sgs.w_ranges; p.block_rng = L.sgs.w_block_rng; p.stream = L.sgs.w_stream; p.ws_ci = L.sgs.w_ws_ci;
+    p.ci_row = L.sgs.w_ci_row; p.ycur = L.sgs.w_ycur; p.y = y; p.omega = ctx->omega; p.y_slots = L.sgs.w_y_slots;
+    p.row_ci = L.sgs.w_row_ci; p.rpos_f = L.sgs.w_rpos_f; p.rpos_b = L.sgs.w_rpos_b; p.iso_diag = L.sgs.w_iso_diag;
+    p.iso_invd = L.sgs.w_iso_invd; p.r = r; p.n_rows = L.n;
+    hipLaunchKernelGGL(sgs_wave_prepass_kernel, dim3(grid_for(L.n)), dim3(256), 0, ctx->stream, p);
+    if (L.sgs.w_n_coupled > 0) {
+      if (ctx->sgs_profile) return sgs_profile_launch(ctx, L, p);
+      if (ctx->prof_every > 0 && !ctx->ev_e.empty()) {
+        if (ctx->ev3_used == (int)ctx->ev_e.size()) collect_sgs_samples(ctx);  // pool full: drain it (synchronises; profiling runs only)
+        ctx->timed_start = ctx->ev_e[(size_t)ctx->ev3_used]; ctx->timed_stop = ctx->ev_f[(size_t)ctx->ev3_used++];
+        ctx->stats.sgs_substeps += L.sgs.w_steps;
+        ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
+      }
+      launch_timed(ctx, sgs_wave_kernel<false>, dim3(L.sgs.n_blocks), dim3(kSwThreads), (size_t)L.sgs.w_lds_bytes, p);
+    }
+    HIPC(hipGetLastError());
     return GMG_OK;
   }
   HIPC(hipMemsetAsync(y, 0, sizeof(double) * (size_t)L.n, ctx->stream));
@@ -684,6 +725,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
   a.omega = ctx->omega; a.r = r; a.y = y;
   hipLaunchKernelGGL(sgs_sweep_kernel<false>, dim3(L.sgs.n_blocks), dim3(1024), 0, ctx->stream, a);
   hipLaunchKernelGGL(sgs_sweep_kernel<true>, dim3(L.sgs.n_blocks), dim3(1024), 0, ctx->stream, a);
+  HIPC(hipGetLastError());
   return GMG_OK;
 }
 
@@ -833,7 +875,6 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   const DevCSR &A = L0.A;
   if (!A.valid) return fail(ctx, GMG_ERR_INVALID, "level-0 matrix not set");
   int variant = ctx->cg_variant;
-  if (const char *ev = std::getenv("GMG_CG_VARIANT")) variant = std::atoi(ev);  // tuning experiments
   if (l0_partitioned(ctx) || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2)
   {
     ctx->stats.coarse_variant = 2;
@@ -1002,6 +1043,290 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
   return GMG_OK;
 }
 
+void free_sgs(SgsPlan &g) {
+  for (void *p : {(void *)g.stage_ptr, (void *)g.stage_rows, (void *)g.block_row, (void *)g.block_stage, (void *)g.w_ranges,
+                  (void *)g.w_block_rng, (void *)g.w_ws_ci, (void *)g.w_ci_row, (void *)g.w_row_ci, (void *)g.w_rpos_f, (void *)g.w_rpos_b,
+                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd})
+    if (p) (void)hipFree(p);
+  g = SgsPlan();
+}
+
+// Plan of the wavefront sweep (gmg_sgs.hpp): per block the pruned rows, the dependency stages, the steps of both
+// sweep directions, their grouping into LDS-sized ranges, and the record stream in consumption order.
+int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col, const double *val, int n_blocks,
+                   const std::vector<int32_t> &block_row) {
+  SgsPlan &G = L.sgs;
+  G.wave = false;
+  if (n <= 0 || ctx->sgs_disable_wave) return GMG_OK;
+  int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : kSwYSlots;
+  y_cap = std::max(64, std::min(y_cap, kSwYSlots)) & ~1;
+  std::vector<int32_t> row_ci((size_t)n, -1), ci_row, rpos_f, rpos_b, ws_ci, block_rng((size_t)n_blocks + 1, 0);
+  std::vector<double> iso_diag((size_t)n, 0.0), iso_invd((size_t)n, 1.0);
+  std::vector<SwRange> ranges;
+  std::vector<char> stream;
+  int max_ws = 0;
+  int64_t total_steps = 0, total_stages = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
+    const int m = (int)(re - rb);
+    block_rng[(size_t)b] = (int32_t)ranges.size();
+    if (m == 0) continue;
+    // ---- in-block nonzero entries of every row (local column numbers), 1 / a_ii as in setup_diag
+    std::vector<int32_t> prp((size_t)m + 1, 0), pcol;
+    std::vector<double> pval, invd((size_t)m, 1.0);
+    std::vector<char> coupled((size_t)m, 0);
+    std::vector<int32_t> low_cnt((size_t)m + 1, 0);
+    for (int i = 0; i < m; ++i) {
+      double aii = 1.0, dstored = 0.0;
+      for (int64_t k = rp[rb + i]; k < rp[rb + i + 1]; ++k) {
+        const int64_t c = col[k];
+        if (k > rp[rb + i] && c <= col[k - 1]) return GMG_OK;  // the prefix hand-over needs ascending columns: generic sweep
+        if (c == rb + i) { aii = val[k]; dstored = val[k]; }
+        if (c < rb || c >= re || val[k] == 0.0) continue;
+        pcol.push_back((int32_t)(c - rb));
+        pval.push_back(val[k]);
+        if (c != rb + i) {
+          coupled[(size_t)i] = 1; coupled[(size_t)(c - rb)] = 1;
+          low_cnt[(size_t)std::max<int64_t>(i, c - rb) + 1]++;
+        }
+      }
+      prp[(size_t)i + 1] = (int32_t)pcol.size();
+      invd[(size_t)i] = 1.0 / aii;
+      iso_diag[(size_t)(rb + i)] = dstored;
+      iso_invd[(size_t)(rb + i)] = 1.0 / aii;
+    }
+    // ---- stages: stage(i) = 1 + max stage(j) over the j < i coupled to i through a_ij or a_ji
+    for (int i = 0; i < m; ++i) low_cnt[(size_t)i + 1] += low_cnt[(size_t)i];
+    std::vector<int32_t> low((size_t)low_cnt[(size_t)m]), fill(low_cnt.begin(), low_cnt.end() - 1);
+    for (int i = 0; i < m; ++i)
+      for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k)
+        if (pcol[(size_t)k] != i) low[(size_t)fill[(size_t)std::max(i, pcol[(size_t)k])]++] = std::min(i, pcol[(size_t)k]);
+    std::vector<int32_t> stage((size_t)m, 0);
+    int n_stages = 0;
+    std::vector<int32_t> crow;  // coupled rows, ascending
+    for (int i = 0; i < m; ++i) {
+      if (!coupled[(size_t)i]) continue;
+      int st = 0;
+      for (int32_t k = low_cnt[(size_t)i]; k < low_cnt[(size_t)i + 1]; ++k) st = std::max(st, stage[(size_t)low[(size_t)k]] + 1);
+      stage[(size_t)i] = st;
+      n_stages = std::max(n_stages, st + 1);
+      row_ci[(size_t)(rb + i)] = (int32_t)ci_row.size();
+      ci_row.push_back((int32_t)(rb + i));
+      crow.push_back(i);
+    }
+    rpos_f.resize(ci_row.size(), 0);
+    rpos_b.resize(ci_row.size(), 0);
+    if (crow.empty()) continue;
+    total_stages += n_stages;
+    std::vector<int32_t> sptr((size_t)n_stages + 1, 0), by_stage(crow.size());
+    for (int32_t i : crow) sptr[(size_t)stage[(size_t)i] + 1]++;
+    for (int t = 0; t < n_stages; ++t) sptr[(size_t)t + 1] += sptr[(size_t)t];
+    {
+      std::vector<int32_t> pos(sptr.begin(), sptr.end() - 1);
+      for (int32_t i : crow) by_stage[(size_t)pos[(size_t)stage[(size_t)i]]++] = i;
+    }
+    std::vector<int32_t> ws_stamp((size_t)m, -1), own_stamp((size_t)m, -1), tmp_stamp((size_t)m, -1), slot_of((size_t)m, 0);
+    std::vector<int32_t> prefix_pos((size_t)m, 0);  // index (doubles) of the row's prefix field in the backward records
+    std::vector<SwRange> dir_ranges[2];
+    int stamp_id = 0, tmp_id = 0;
+    for (int dir = 1; dir >= 0; --dir) {  // backward first: the forward records point into the backward ones
+      // entries of a row in this direction: forward = the columns j < i (y_j = 0 for j >= i); backward = the columns
+      // j >= i, continuing the forward sum
+      auto in_dir = [&](int i, int c) { return dir == 0 ? c < i : c >= i; };
+      auto n_ent = [&](int i) {
+        int c = 0;
+        for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) c += in_dir(i, pcol[(size_t)k]);
+        return c;
+      };
+      // ---- steps: <= 64 rows of one stage, records of a sub-step <= kSwMaxBlock bytes, working set <= y_cap
+      struct Step { int32_t first, nrows, len; };
+      std::vector<int32_t> seq;
+      std::vector<Step> steps;
+      seq.reserve(crow.size());
+      for (int t = 0; t < n_stages; ++t) {
+        const int tt = dir == 0 ? t : n_stages - 1 - t;
+        Step cur{(int32_t)seq.size(), 0, 0};
+        for (int32_t q = sptr[(size_t)tt]; q < sptr[(size_t)tt + 1]; ++q) {
+          const int i = by_stage[(size_t)q];
+          const int li = n_ent(i);
+          const int nl = std::max(cur.len, li);
+          const int64_t raw = 16 + (int64_t)(cur.nrows + 1) * kSwStride;
+          if (cur.nrows > 0 && (cur.nrows == 64 || raw > kSwMaxBlock || (cur.nrows + 1) * (nl + 1) > y_cap)) {
+            steps.push_back(cur);
+            cur = Step{(int32_t)seq.size(), 0, 0};
+          }
+          cur.len = std::max(cur.len, li);
+          cur.nrows++;
+          seq.push_back(i);
+        }
+        if (cur.nrows) steps.push_back(cur);
+      }
+      // ---- ranges: greedy runs of steps whose rows + referenced rows fit y_cap
+      size_t s0 = 0;
+      while (s0 < steps.size()) {
+        ++stamp_id;
+        int ws = 0;
+        size_t s1 = s0;
+        while (s1 < steps.size()) {
+          ++tmp_id;
+          int add = 0;
+          const Step &S = steps[s1];
+          for (int u = 0; u < S.nrows; ++u) {
+            const int i = seq[(size_t)(S.first + u)];
+            if (ws_stamp[(size_t)i] != stamp_id && tmp_stamp[(size_t)i] != tmp_id) { tmp_stamp[(size_t)i] = tmp_id; ++add; }
+            for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
+              const int c = pcol[(size_t)k];
+              if (!in_dir(i, c)) continue;
+              if (ws_stamp[(size_t)c] != stamp_id && tmp_stamp[(size_t)c] != tmp_id) { tmp_stamp[(size_t)c] = tmp_id; ++add; }
+            }
+          }
+          if (ws + add > y_cap && s1 > s0) break;
+          if (ws + add > y_cap) return fail(ctx, GMG_ERR_UNSUPPORTED, "SGS plan: one step exceeds the LDS working set");
+          ws += add;
+          for (int u = 0; u < S.nrows; ++u) {
+            const int i = seq[(size_t)(S.first + u)];
+            ws_stamp[(size_t)i] = stamp_id;
+            for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k)
+              if (in_dir(i, pcol[(size_t)k])) ws_stamp[(size_t)pcol[(size_t)k]] = stamp_id;
+          }
+          ++s1;
+        }
+        // slots: rows updated here first (step order), then the rows only read (first touch)
+        SwRange R{};
+        R.ws_off = (int32_t)ws_ci.size();
+        int n_slot = 0;
+        for (size_t st = s0; st < s1; ++st)
+          for (int u = 0; u < steps[st].nrows; ++u) {
+            const int i = seq[(size_t)(steps[st].first + u)];
+            own_stamp[(size_t)i] = stamp_id;
+            slot_of[(size_t)i] = n_slot++;
+            ws_ci.push_back(row_ci[(size_t)(rb + i)]);
+          }
+        R.n_own = n_slot;
+        for (size_t st = s0; st < s1; ++st)
+          for (int u = 0; u < steps[st].nrows; ++u) {
+            const int i = seq[(size_t)(steps[st].first + u)];
+            for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
+              const int c = pcol[(size_t)k];
+              if (!in_dir(i, c) || own_stamp[(size_t)c] == stamp_id) continue;
+              own_stamp[(size_t)c] = stamp_id;  // now "has a slot"
+              slot_of[(size_t)c] = n_slot++;
+              ws_ci.push_back(row_ci[(size_t)(rb + c)]);
+            }
+          }
+        R.n_ws = n_slot;
+        max_ws = std::max(max_ws, n_slot);
+        R.backward = dir;
+        R.n_steps = 0;
+        // ---- records in consumption order; a block never straddles the end of the ring
+        const int64_t base = ((int64_t)stream.size() + kSwChunk - 1) / kSwChunk * kSwChunk;
+        R.stream_off = base;
+        int64_t off = 0, prev_hdr = -1;
+        for (size_t st = s0; st < s1; ++st) {
+          const Step &S = steps[st];
+          const int nr = S.nrows;
+          const int n_sub = std::max(1, (S.len + kSwW - 1) / kSwW);
+          const int64_t raw = 16 + (int64_t)nr * kSwStride;
+          for (int sub = 0; sub < n_sub; ++sub) {
+            if (off % kSwRing + raw > kSwRing) off = (off / kSwRing + 1) * kSwRing;
+            stream.resize((size_t)(base + off + raw), 0);
+            char *blk = stream.data() + base + off;
+            SwStepHdr h{};
+            h.nrows = (uint16_t)nr;
+            h.flags = (uint16_t)((sub == 0 ? 1 : 0) | (sub == n_sub - 1 ? 2 : 0));
+            std::memcpy(blk, &h, sizeof h);
+            if (prev_hdr >= 0) {
+              SwStepHdr ph;
+              std::memcpy(&ph, stream.data() + base + prev_hdr, sizeof ph);
+              ph.advance = (uint32_t)(off - prev_hdr); ph.next_raw = (uint32_t)raw; ph.next_nrows = (uint32_t)nr;
+              std::memcpy(stream.data() + base + prev_hdr, &ph, sizeof ph);
+            } else {
+              R.first_raw = (int32_t)raw; R.first_nrows = nr;
+            }
+            prev_hdr = off;
+            for (int u = 0; u < nr; ++u) {
+              const int i = seq[(size_t)(S.first + u)];
+              const int32_t ci = row_ci[(size_t)(rb + i)];
+              char *rec = blk + 16 + (size_t)u * kSwStride;
+              const int64_t rec_pos = base + off + 16 + (int64_t)u * kSwStride;
+              if (sub == n_sub - 1) (dir == 0 ? rpos_f : rpos_b)[(size_t)ci] = (int32_t)(rec_pos / 8);  // the rhs is read when the row is finished
+              if (dir == 1 && sub == 0) prefix_pos[(size_t)i] = (int32_t)(rec_pos / 8 + 2);             // the prefix when it is started
+              double *f = reinterpret_cast<double *>(rec);
+              uint32_t *w = reinterpret_cast<uint32_t *>(rec);
+              const uint32_t my = (uint32_t)slot_of[(size_t)i] * 8u;
+              f[0] = 0.0; f[1] = invd[(size_t)i]; f[2] = 0.0;
+              w[6] = my;
+              w[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
+              uint32_t *ad = reinterpret_cast<uint32_t *>(rec + 32 + 8 * kSwW);
+              int e = 0, seen = 0;
+              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1] && e < kSwW; ++k) {
+                const int c = pcol[(size_t)k];
+                if (!in_dir(i, c)) continue;
+                if (seen++ < sub * kSwW) continue;  // entries of earlier sub-steps
+                f[4 + e] = pval[(size_t)k];
+                ad[e++] = (uint32_t)slot_of[(size_t)c] * 8u;
+              }
+              for (; e < kSwW; ++e) { f[4 + e] = 0.0; ad[e] = my; }
+            }
+            off += raw;
+            R.n_steps++;
+          }
+        }
+        if (prev_hdr >= 0) {  // last step: advance = its own size, nothing follows
+          SwStepHdr ph;
+          std::memcpy(&ph, stream.data() + base + prev_hdr, sizeof ph);
+          ph.advance = (uint32_t)(off - prev_hdr); ph.next_raw = 0;
+          std::memcpy(stream.data() + base + prev_hdr, &ph, sizeof ph);
+        }
+        const int64_t padded = (off + kSwChunk - 1) / kSwChunk * kSwChunk;
+        if (padded >= ((int64_t)1 << 31) || (base + padded) / 8 >= ((int64_t)1 << 31)) return GMG_OK;  // generic sweep
+        stream.resize((size_t)(base + padded), 0);
+        R.stream_bytes = (int32_t)padded;
+        total_steps += R.n_steps;
+        dir_ranges[dir].push_back(R);
+        s0 = s1;
+      }
+    }
+    for (int dir = 0; dir < 2; ++dir) ranges.insert(ranges.end(), dir_ranges[dir].begin(), dir_ranges[dir].end());
+  }
+  block_rng[(size_t)n_blocks] = (int32_t)ranges.size();
+  const int y_slots = std::max(2, (max_ws + 1) & ~1);
+#define SW_UP(dst, vec, T)                                                                                          \
+  HIPC(hipMalloc(&dst, sizeof(T) * std::max<size_t>((vec).size(), 1)));                                              \
+  if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
+  SW_UP(G.w_ranges, ranges, SwRange)
+  SW_UP(G.w_block_rng, block_rng, int32_t)
+  SW_UP(G.w_ws_ci, ws_ci, int32_t)
+  SW_UP(G.w_ci_row, ci_row, int32_t)
+  SW_UP(G.w_row_ci, row_ci, int32_t)
+  SW_UP(G.w_rpos_f, rpos_f, int32_t)
+  SW_UP(G.w_rpos_b, rpos_b, int32_t)
+  SW_UP(G.w_stream, stream, char)
+  SW_UP(G.w_iso_diag, iso_diag, double)
+  SW_UP(G.w_iso_invd, iso_invd, double)
+#undef SW_UP
+  HIPC(hipMalloc(&G.w_ycur, sizeof(double) * std::max<size_t>(ci_row.size(), 1)));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  G.w_y_slots = y_slots;
+  G.w_lds_bytes = y_slots * 8 + kSwRing + 16;
+  G.w_n_ranges = (int)ranges.size();
+  G.w_n_coupled = (int64_t)ci_row.size();
+  G.w_stream_bytes = (int64_t)stream.size();
+  G.w_steps = total_steps; G.w_stages = total_stages;
+  HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // the sweep bakes absolute LDS addresses into its records: its dynamic LDS must start at 0 (no static __shared__)
+  hipFuncAttributes fa{};
+  HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_wave_kernel<false>));
+  G.wave = fa.sharedSizeBytes == 0;
+  if (ctx->debug_upload)
+    std::fprintf(stderr, "[gmg] SGS wave plan: %lld rows, %lld coupled, %d blocks, %lld stages, %lld sub-steps, %d ranges, y slots %d, stream %.1f MB\n",
+                 (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
+                 (double)stream.size() / 1e6);
+  return GMG_OK;
+}
+
+
 // SGS level schedule on the symmetrised pattern, per block of consecutive rows:
 // stage(i) = 1 + max stage(j) over the coupled j < i of the same block.
 int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col, const double *val) {
@@ -1037,8 +1362,7 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
     block_stage[(size_t)b + 1] = block_stage[(size_t)b] + ns;
     n_stages_max = std::max(n_stages_max, ns);
   }
-  for (int32_t **p : {&L.sgs.stage_ptr, &L.sgs.stage_rows, &L.sgs.block_row, &L.sgs.block_stage})
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  free_sgs(L.sgs);
   L.sgs.n_blocks = n_blocks; L.sgs.n_stages_max = n_stages_max;
   HIPC(hipMalloc(&L.sgs.stage_ptr, sizeof(int32_t) * std::max<size_t>(sp.size(), 1)));
   HIPC(hipMalloc(&L.sgs.stage_rows, sizeof(int32_t) * rows.size()));
@@ -1049,102 +1373,7 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
   HIPC(hipMemcpyAsync(L.sgs.block_row, block_row.data(), sizeof(int32_t) * block_row.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(L.sgs.block_stage, block_stage.data(), sizeof(int32_t) * block_stage.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
-  // ---- packed / LDS variant when every block's y slice fits the LDS
-  for (void **p : {(void **)&L.sgs.block_slot, (void **)&L.sgs.slot_row, (void **)&L.sgs.block_w, (void **)&L.sgs.step_last,
-                   (void **)&L.sgs.block_pk, (void **)&L.sgs.pk_val, (void **)&L.sgs.pk_col, (void **)&L.sgs.pk_col32, (void **)&L.sgs.slot_invd,
-                   (void **)&L.sgs.r_slot})
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
-  L.sgs.packed = false; L.sgs.packed_global = false;
-  int max_rows = 0;
-  for (int b = 0; b < n_blocks; ++b) max_rows = std::max(max_rows, block_row[(size_t)b + 1] - block_row[(size_t)b]);
-  const char *no_pk = std::getenv("GMG_DISABLE_SGS_PACKED");
-  const char *lds_rows_env = std::getenv("GMG_SGS_LDS_ROWS");  // tests: a small value sends small blocks down the global-y variant
-  const int lds_rows = lds_rows_env ? std::atoi(lds_rows_env) : kSgsLdsRows;
-  const bool global_y = max_rows > lds_rows;  // blocks too big for the LDS keep y in global memory (same records, int32 columns)
-  if (max_rows > 0 && !(no_pk && no_pk[0] == '1')) {
-    std::vector<int32_t> block_slot((size_t)n_blocks + 1, 0), slot_row, block_w((size_t)n_blocks, 32);
-    std::vector<uint8_t> step_last;
-    std::vector<int64_t> block_pk((size_t)n_blocks, 0);
-    std::vector<double> slot_invd;
-    int64_t total = 0;
-    int max_lds = 0;
-    for (int b = 0; b < n_blocks; ++b) {
-      const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
-      int w = 1;
-      for (int64_t i = rb; i < re; ++i) {
-        int c = 0;
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) c += (col[k] >= rb && col[k] < re);
-        w = std::max(w, c);
-      }
-      block_w[(size_t)b] = (w + 31) / 32 * 32;
-      // slots: each stage padded to a multiple of 32 rows
-      const int so = block_stage[(size_t)b] + b, ns = block_stage[(size_t)b + 1] - block_stage[(size_t)b];
-      const size_t slot0 = slot_row.size();
-      for (int t = 0; t < ns; ++t) {
-        const int qb = sp[(size_t)(so + t)], qe = sp[(size_t)(so + t + 1)];
-        for (int q = qb; q < qe; q += 32) {
-          for (int u = 0; u < 32; ++u) slot_row.push_back(q + u < qe ? rows[(size_t)(q + u)] : -1);
-          step_last.push_back(q + 32 >= qe ? 1 : 0);
-        }
-      }
-      block_slot[(size_t)b + 1] = (int32_t)slot_row.size();
-      block_pk[(size_t)b] = total;
-      total += (int64_t)(slot_row.size() - slot0) * block_w[(size_t)b];
-      const int n_steps = (int)((slot_row.size() - slot0) / 32);
-      max_lds = std::max(max_lds, (int)((global_y ? 0 : 8 * (re - rb)) + ((n_steps + 15) / 16) * 16));
-    }
-    if (max_lds <= 160 * 1024 && total < ((int64_t)1 << 31)) {
-      const size_t n_slots = slot_row.size();
-      std::vector<double> pk_val((size_t)std::max<int64_t>(total, 1), 0.0);
-      std::vector<uint16_t> pk_col(global_y ? 1 : (size_t)std::max<int64_t>(total, 1), 0);
-      std::vector<int32_t> pk_col32(global_y ? (size_t)std::max<int64_t>(total, 1) : 1, 0);
-      auto set_col = [&](int64_t o, int64_t c_local) {
-        if (global_y) pk_col32[(size_t)o] = (int32_t)c_local;
-        else pk_col[(size_t)o] = (uint16_t)c_local;
-      };
-      slot_invd.assign(std::max<size_t>(n_slots, 1), 0.0);
-      for (int b = 0; b < n_blocks; ++b) {
-        const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
-        const int w = block_w[(size_t)b];
-        for (int64_t sl = block_slot[(size_t)b]; sl < block_slot[(size_t)b + 1]; ++sl) {
-          const int64_t i = slot_row[(size_t)sl];
-          const int64_t o = block_pk[(size_t)b] + (sl - block_slot[(size_t)b]) * w;
-          if (i < 0) continue;  // padding slot: zero records, never executed (row = -1)
-          int c = 0;
-          double aii = 1.0;
-          for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
-            if (col[k] == i) aii = val[k];
-            if (col[k] >= rb && col[k] < re) { pk_val[(size_t)(o + c)] = val[k]; set_col(o + c, col[k] - rb); ++c; }
-          }
-          for (; c < w; ++c) { pk_val[(size_t)(o + c)] = 0.0; set_col(o + c, i - rb); }
-          slot_invd[(size_t)sl] = 1.0 / aii;
-        }
-      }
-#define SGS_UP(dst, vec, T)                                                                                         \
-  HIPC(hipMalloc(&dst, sizeof(T) * std::max<size_t>((vec).size(), 1)));                                              \
-  if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
-      SGS_UP(L.sgs.block_slot, block_slot, int32_t)
-      SGS_UP(L.sgs.slot_row, slot_row, int32_t)
-      SGS_UP(L.sgs.step_last, step_last, uint8_t)
-      SGS_UP(L.sgs.block_w, block_w, int32_t)
-      SGS_UP(L.sgs.block_pk, block_pk, int64_t)
-      SGS_UP(L.sgs.pk_val, pk_val, double)
-      SGS_UP(L.sgs.pk_col, pk_col, uint16_t)
-      SGS_UP(L.sgs.pk_col32, pk_col32, int32_t)
-      SGS_UP(L.sgs.slot_invd, slot_invd, double)
-#undef SGS_UP
-      HIPC(hipMalloc(&L.sgs.r_slot, sizeof(double) * std::max<size_t>(n_slots, 1)));
-      HIPC(hipStreamSynchronize(ctx->stream));
-      L.sgs.packed = true;
-      L.sgs.packed_global = global_y;
-      L.sgs.max_block_rows = max_rows;
-      L.sgs.n_slots = (int)n_slots;
-      L.sgs.lds_bytes = max_lds;
-      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void *)sgs_packed_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-  }
-  return GMG_OK;
+  return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row);
 }
 
 // frees every operator / work vector but keeps the stream, the reduction scratch and the communicator
@@ -1163,10 +1392,7 @@ void release_operators(gmg_context *ctx) {
       if (p) (void)hipFree(p);
     if (L.copy_g) (void)hipFree(L.copy_g);
     if (L.copy_l) (void)hipFree(L.copy_l);
-    for (void *p : {(void *)L.sgs.stage_ptr, (void *)L.sgs.stage_rows, (void *)L.sgs.block_row, (void *)L.sgs.block_stage,
-                    (void *)L.sgs.block_slot, (void *)L.sgs.slot_row, (void *)L.sgs.block_w, (void *)L.sgs.step_last,
-                    (void *)L.sgs.block_pk, (void *)L.sgs.pk_val, (void *)L.sgs.pk_col, (void *)L.sgs.pk_col32, (void *)L.sgs.slot_invd, (void *)L.sgs.r_slot})
-      if (p) (void)hipFree(p);
+    free_sgs(L.sgs);
     L = Level();
   }
   free_csr(ctx->S);
@@ -1211,6 +1437,23 @@ int gmg_create(gmg_context **out, int device_id, int n_levels) {
   if (hipMalloc(&ctx->scal_dev, sizeof(double) * 8) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipHostMalloc((void **)&ctx->scal_host, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess) return bail(GMG_ERR_HIP);
   (void)hipMemsetAsync(ctx->st, 0, sizeof(CGState), ctx->stream);
+  // measurement scripts reach the diagnostic options of a context they do not create themselves through
+  // GMG_OPTIONS="key=value,key=value" (same keys as gmg_set_option); unknown keys fail the creation
+  if (const char *env = std::getenv("GMG_OPTIONS")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string item = all.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t eq = item.find('=');
+      if (item.empty()) continue;
+      const std::string key = eq == std::string::npos ? item : item.substr(0, eq);
+      const double v = eq == std::string::npos ? 1.0 : std::atof(item.c_str() + eq + 1);
+      if (gmg_set_option(ctx, key.c_str(), v) != GMG_OK) return bail(GMG_ERR_INVALID);
+    }
+  }
   *out = ctx;
   return GMG_OK;
 }
@@ -1228,7 +1471,7 @@ int gmg_destroy(gmg_context *ctx) {
   for (auto &e : ctx->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (ctx->scal_host) (void)hipHostFree(ctx->scal_host);
-  for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d})
+  for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d, &ctx->ev_e, &ctx->ev_f})
     for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1244,6 +1487,7 @@ int gmg_reset(gmg_context *ctx, int n_levels) {
   ctx->lv.assign((size_t)n_levels, Level());
   ctx->last_coarse_iters = 0;
   ctx->stats = gmg_stats{};
+  ctx->ev3_used = 0;
   return GMG_OK;
 }
 
@@ -1741,6 +1985,7 @@ int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_
 
 int gmg_stats_reset(gmg_context *ctx) {
   if (!ctx) return GMG_ERR_INVALID;
+  collect_sgs_samples(ctx);
   const gmg_stats keep = ctx->stats;
   ctx->stats = gmg_stats{};
   ctx->stats.spmv0_rows = keep.spmv0_rows; ctx->stats.spmv0_nnz = keep.spmv0_nnz; ctx->stats.coarse_variant = keep.coarse_variant;
@@ -1750,6 +1995,7 @@ int gmg_stats_reset(gmg_context *ctx) {
 }
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out) {
   if (!ctx || !out) return GMG_ERR_INVALID;
+  collect_sgs_samples(ctx);
   *out = ctx->stats;
   return GMG_OK;
 }
@@ -1757,7 +2003,7 @@ int gmg_set_profiling(gmg_context *ctx, int sample_every) {
   if (!ctx || sample_every < 0) return GMG_ERR_INVALID;
   ctx->prof_every = sample_every;
   if (sample_every > 0 && ctx->ev_a.empty()) {
-    for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d}) {
+    for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d, &ctx->ev_e, &ctx->ev_f}) {
       v->resize(256);
       for (auto &e : *v) HIPC(hipEventCreate(&e));
     }
@@ -1796,6 +2042,27 @@ int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_
   if (copy_gbps) *copy_gbps = (double)n2 * 32 * reps / (ms * 1e-3) / 1e9;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(a); (void)hipFree(b);
+  return GMG_OK;
+}
+
+int gmg_set_option(gmg_context *ctx, const char *key, double value) {
+  if (!ctx || !key) return GMG_ERR_INVALID;
+  const std::string k(key);
+  const bool on = value != 0.0;
+  if (k == "host_threads") g_host_threads = (int)value;
+  else if (k == "debug_upload") ctx->debug_upload = on;
+  else if (k == "disable_sell") ctx->disable_sell = on;
+  else if (k == "disable_patterns") ctx->disable_patterns = on;
+  else if (k == "disable_compression") ctx->disable_compression = on;
+  else if (k == "disable_sellp") ctx->disable_sellp = on;
+  else if (k == "sell_grid") ctx->sell_grid = (int)value;
+  else if (k == "sellp_cost") ctx->sellp_cost = value;
+  else if (k == "cg_variant") ctx->cg_variant = (int)value;
+  else if (k == "coarse_chunk") ctx->coarse_chunk = (int)value;
+  else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
+  else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
+  else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }
+  else return fail(ctx, GMG_ERR_INVALID, "gmg_set_option: unknown key");
   return GMG_OK;
 }
 

@@ -1023,7 +1023,8 @@ __global__ __launch_bounds__(kThreads) void stream_copy_kernel(const double2 *x,
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kThreads) y[i] = x[i];
 }
 
-// ---------------------------------------------------------------- SSOR (level-scheduled SGS)
+// ---------------------------------------------------------------- SSOR (level-scheduled SGS), generic fallback
+// (the production path is the wavefront sweep of gmg_sgs.hpp; this one takes any row width straight from the CSR copy)
 // Ifpack's symmetric Gauss-Seidel is sequential in the local row order; rows without mutual
 // coupling form "stages" (computed on the host), so sweeping stage by stage reproduces the
 // sequential result exactly.  One workgroup (1024 threads = 32 half-waves) owns one block of
@@ -1075,113 +1076,6 @@ __global__ __launch_bounds__(1024) void sgs_sweep_kernel(SgsArgs a) {
     __threadfence_block();
     __syncthreads();
   }
-}
-
-// Packed variant for blocks of <= kSgsLdsRows rows: the block's slice of y lives in LDS for the
-// whole symmetric sweep (forward + backward in ONE launch).  The schedule is laid out in slots:
-// every stage is padded to a multiple of 32 rows, a step = 32 consecutive slots = one row per
-// half-wave, and everything a half-wave needs for its slot -- the row's in-block entries as
-// fixed-width (16-bit local column, value) records, 1/a_ii, the local row number and r (gathered
-// into slot order by a tiny kernel before the sweep) -- sits at an address that depends on the
-// slot number only.  A step therefore costs one coalesced, fully prefetchable global load, LDS
-// gathers, the in-order shuffle sum and (at stage ends) one barrier: no dependent global round
-// trip.  Same arithmetic in the same order as the sequential sweep.
-constexpr int kSgsLdsRows = 16384;
-
-struct SgsPackedArgs {
-  const int32_t *block_row;   // n_blocks + 1: rows of each block
-  const int32_t *block_slot;  // n_blocks + 1: schedule slots of each block (multiples of 32)
-  const int64_t *block_pk;    // n_blocks: offset of the block's records
-  const int32_t *block_w;     // n_blocks: record width (multiple of 32)
-  const int32_t *slot_row;    // slot -> global row, -1 = padding
-  const double *slot_invd;    // slot -> 1/a_ii
-  const uint8_t *step_last;   // step (= slot / 32) -> 1 if it closes its stage
-  const double *pk_val;       // [slot][width of its block]
-  const uint16_t *pk_col;     // local column in the block (LDS variant)
-  const int32_t *pk_col32;    // the same as int32 (blocks above kSgsLdsRows rows: y stays in global memory)
-  double omega;
-  const double *r;            // level vector (global row order)
-  double *r_slot;             // scratch: r in slot order
-  double *y;
-  int n_slots;
-};
-
-// r_slot[s] = r[slot_row[s]]
-__global__ __launch_bounds__(kThreads) void sgs_gather_rhs_kernel(SgsPackedArgs a) {
-  for (int s = blockIdx.x * kThreads + threadIdx.x; s < a.n_slots; s += gridDim.x * kThreads) {
-    const int row = a.slot_row[s];
-    a.r_slot[s] = row >= 0 ? a.r[row] : 0.0;
-  }
-}
-
-// GLOBAL_Y = false: the block's slice of y lives in LDS.  GLOBAL_Y = true (blocks of more than kSgsLdsRows
-// rows): y stays in global memory -- the waves of the one workgroup share the CU's L1, stage ends are a
-// block-scope fence + barrier -- and only the stage-end flags sit in LDS; records and schedule are the same.
-template <bool GLOBAL_Y>
-__global__ __launch_bounds__(1024) void sgs_packed_kernel(SgsPackedArgs a) {
-  extern __shared__ double ylds[];
-  const int b = blockIdx.x;
-  const int rb = a.block_row[b], nrows = a.block_row[b + 1] - rb;
-  const int s0 = a.block_slot[b], n_steps = (a.block_slot[b + 1] - s0) >> 5;
-  const int W = a.block_w[b];
-  const int64_t pk0 = a.block_pk[b];
-  double *yv = GLOBAL_Y ? a.y + rb : ylds;
-  uint8_t *last = reinterpret_cast<uint8_t *>(GLOBAL_Y ? ylds : ylds + nrows);
-  const int hw = threadIdx.x >> 5, hl = threadIdx.x & 31;
-  for (int i = threadIdx.x; i < nrows; i += 1024) yv[i] = 0.0;
-  for (int i = threadIdx.x; i < n_steps; i += 1024) last[i] = a.step_last[(s0 >> 5) + i];
-  if constexpr (GLOBAL_Y) __threadfence_block();
-  __syncthreads();
-  auto col_at = [&](int64_t o) -> int {
-    if constexpr (GLOBAL_Y) return a.pk_col32[o];
-    else return a.pk_col[o];
-  };
-  for (int dir = 0; dir < 2; ++dir) {
-    // forward: steps 0 .. n-1; backward: n-1 .. 0 (stages in reverse order; the steps of one stage
-    // are mutually independent, so their order inside the stage does not matter)
-    double pv = 0.0, pr = 0.0, pinv = 0.0;
-    int pc = 0, prow = -1;
-    auto prefetch = [&](int t) {
-      prow = -1;
-      if (t < 0 || t >= n_steps) return;
-      const int slot = s0 + (t << 5) + hw;
-      prow = a.slot_row[slot];
-      const int64_t o = pk0 + (int64_t)(slot - s0) * W + hl;
-      pv = a.pk_val[o];
-      pc = col_at(o);
-      pr = a.r_slot[slot];
-      pinv = a.slot_invd[slot];
-    };
-    const int t_first = dir == 0 ? 0 : n_steps - 1, dt = dir == 0 ? 1 : -1;
-    prefetch(t_first);
-    for (int it = 0, t = t_first; it < n_steps; ++it, t += dt) {
-      const double cv = pv, cr = pr, cinv = pinv;
-      const int cc = pc, crow = prow;
-      prefetch(t + dt);
-      if (crow >= 0) {
-        double acc = 0.0;
-        double prod = cv * yv[cc];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc += __shfl(prod, k, 32);
-        for (int kb = 32; kb < W; kb += 32) {  // rows wider than 32 in-block entries (rare)
-          const int64_t o = pk0 + (int64_t)((t << 5) + hw) * W + kb + hl;
-          prod = a.pk_val[o] * yv[col_at(o)];
-#pragma unroll
-          for (int k = 0; k < 32; ++k) acc += __shfl(prod, k, 32);
-        }
-        if (hl == 0) yv[crow - rb] += a.omega * (cr - acc) * cinv;
-      }
-      const bool end_stage = dir == 0 ? last[t] != 0 : (t == 0 || last[t - 1] != 0);
-      if (end_stage) {
-        if constexpr (GLOBAL_Y) __threadfence_block();
-        __syncthreads();
-      }
-    }
-    if constexpr (GLOBAL_Y) __threadfence_block();
-    __syncthreads();
-  }
-  if constexpr (!GLOBAL_Y)
-    for (int i = threadIdx.x; i < nrows; i += 1024) a.y[rb + i] = ylds[i];
 }
 
 }  // namespace gmg

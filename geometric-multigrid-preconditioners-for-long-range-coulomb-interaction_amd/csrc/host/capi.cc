@@ -105,6 +105,10 @@ int step50_run_cycle(step50_problem *h, int cycle, int on_device) {
 int step50_solve_again(step50_problem *h) {
   return guarded(h, [&] { return DISPATCH(h, solve_again()); });
 }
+// bench: re-upload the current cycle's operators with another smoother
+int step50_set_smoother(step50_problem *h, const char *smoother, int ssor_blocks) {
+  return guarded(h, [&] { return DISPATCH(h, set_smoother(std::string(smoother), ssor_blocks)); });
+}
 // CPU-only continuation of a cycle for tests: inject a solution, then estimator + energy
 int step50_finish_cycle_with(step50_problem *h, const double *x, int64_t n) {
   return guarded(h, [&] {

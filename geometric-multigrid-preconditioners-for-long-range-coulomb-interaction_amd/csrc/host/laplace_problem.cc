@@ -1179,6 +1179,17 @@ int LaplaceProblem<dim>::solve_again() {
   return rc;
 }
 
+// bench: the operators of the current cycle with another smoother ("Jacobi" | "SSOR" | "Chebyshev"; SSOR in
+// `ssor_blocks` blocks = the reference's smoother on that many ranks).  The SGS schedule is built at upload.
+template <int dim>
+int LaplaceProblem<dim>::set_smoother(const std::string &smoother, int ssor_blocks) {
+  if (smoother != "Jacobi" && smoother != "SSOR" && smoother != "Chebyshev") { last_error = "unknown smoother " + smoother; return GMG_ERR_INVALID; }
+  if (!operators_uploaded) { last_error = "set_smoother: no cycle has been run"; return GMG_ERR_INVALID; }
+  par.smoother = smoother;
+  par.ssor_blocks = std::max(1, ssor_blocks);
+  return upload();
+}
+
 template <int dim>
 void LaplaceProblem<dim>::distribute_constraints(std::vector<double> &u) const {
   for (size_t i = 0; i < constraint_of_dof.size(); ++i) {

@@ -113,6 +113,7 @@ class LaplaceProblem {
   void finish_cycle();                                   // estimator + energy, the tail of the loop body
   void set_solution(const std::vector<double> &x);       // test hook, see laplace_problem.cc
   int solve_again();  // repeat the solve of the current cycle from the same initial guess (bench step)
+  int set_smoother(const std::string &smoother, int ssor_blocks);  // other smoother on the current cycle's operators (re-uploads them)
 
   // ---- data, named as in the reference where it exists (include/step_50.h:146-200)
   Parameters par;

@@ -143,6 +143,10 @@ class Problem:
         self._chk(self.L.step50_solve_again(self.h), "solve")
         return self.report(-1)
 
+    def set_smoother(self, smoother: str, ssor_blocks: int = 1):
+        """Another smoother on the operators of the cycle just run (re-uploads them; the next solve_again uses it)."""
+        self._chk(self.L.step50_set_smoother(self.h, smoother.encode(), C.c_int(ssor_blocks)), "set_smoother")
+
     def report(self, i=-1) -> dict:
         r = Report()
         self._chk(self.L.step50_get_report(self.h, C.c_int(i), C.byref(r)), "get_report")

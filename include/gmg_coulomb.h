@@ -180,6 +180,10 @@ typedef struct gmg_stats {
   int64_t coarse_enqueued;      /* coarse iterations enqueued, incl. those that returned at once after convergence */
   int64_t spmv0_noop_samples;   /* sampled level-0 launches that returned at once (after convergence): ...    */
   double spmv0_noop_ms_total;   /* ... their summed event time                                                */
+  int64_t sgs_samples;          /* SSOR sweep launches (levels >= 1) bracketed by HIP events while profiling is on   */
+  double sgs_ms_total;          /* their summed event time                                                           */
+  int64_t sgs_substeps;         /* dependent sub-steps those launches walked (the sweep is latency bound)            */
+  int64_t sgs_stream_bytes;     /* record bytes they streamed                                                        */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
@@ -192,6 +196,13 @@ int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_
  * from the previous solve); cg_variant = 0 auto by size, 1 fused two-kernel iteration (SpMV also
  * forms d = beta d - g), 2 three-kernel iteration.                                          */
 int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant);
+/* Diagnostic / measurement options by name (defaults are the production paths).  Keys: host_threads,
+ * debug_upload, disable_sell, disable_patterns, disable_compression, disable_sellp, sell_grid, sellp_cost,
+ * cg_variant, coarse_chunk, sgs_y_slots (doubles of LDS the SSOR sweep may use for y: small values force
+ * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep).  Options that shape a device
+ * layout take effect at the next gmg_set_*_matrix.  The same keys are read once from the environment
+ * variable GMG_OPTIONS="key=value,..." at gmg_create (for profiling scripts around bench.py).        */
+int gmg_set_option(gmg_context *ctx, const char *key, double value);
 /* SSOR blocks B: 1 = exact sequential sweep (the reference on one rank); B > 1 = what the
  * reference's smoother does on B MPI ranks: symmetric Gauss-Seidel inside each block of
  * consecutive rows, couplings between blocks dropped (Ifpack's rank-local matrix).  Call before

@@ -237,15 +237,12 @@ def test_single_rank_communicator_path(hier45):
     c.close()
 
 
-@pytest.mark.parametrize("blocks,variant", [(3, "lds"), (16, "lds"), (1, "global"), (3, "global"), (1, "sweep"), (3, "sweep")])
-def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant, monkeypatch):
-    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the three
-    device variants: slot-addressed records with y in LDS (blocks up to 16 k rows), the same records with y
-    in global memory (bigger blocks; forced here by GMG_SGS_LDS_ROWS), and the plain CSR sweep."""
-    if variant == "global":
-        monkeypatch.setenv("GMG_SGS_LDS_ROWS", "100")
-    if variant == "sweep":
-        monkeypatch.setenv("GMG_DISABLE_SGS_PACKED", "1")
+@pytest.mark.parametrize("blocks,variant", [(1, "wave"), (3, "wave"), (16, "wave"), (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
+def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
+    """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the device
+    variants: the wavefront sweep with y in LDS (gmg_sgs.hpp) with a block's rows in one LDS range, the same
+    with the LDS budget cut to 300 doubles so that every block is swept in many ranges (working sets written
+    back / reloaded in between), and the generic CSR sweep."""
     level = 4
     n = hier3.level_matrices[level].n_rows
     rng = np.random.default_rng(7)
@@ -253,6 +250,10 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant, monkeypatch
     mg = go.OracleMG(hier3, smoother=go.SSOR, ssor_blocks=blocks)
     c = capi().Context(len(hier3.level_matrices))
     c.set_tuning(ssor_blocks=blocks)
+    if variant == "ranges":
+        c.set_option("sgs_y_slots", 300)
+    if variant == "sweep":
+        c.set_option("sgs_disable_wave", 1)
     c.load_hierarchy(hier3)
     c.set_smoother(capi().SSOR, 0.5, 2)
     for from_zero in (True, False):

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Times the SSOR sweep (gmg_smoother_step, from zero: one application) on the level operators of a BASELINE
+config after `cycles` adaptive cycles.  GMG_OPTIONS=sgs_profile=<1+mode> prints the in-kernel cycle counters."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("geometric-multigrid-preconditioners-for-long-range-coulomb-interaction_amd")
+S, capi = pkg.step50, pkg.capi
+nacl = int(sys.argv[1]); cycles = int(sys.argv[2]); blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+opts = os.environ.pop("GMG_OPTIONS", "")
+p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+                         cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi"))
+p.set_nacl_atoms(nacl)
+for c in range(cycles):
+    r = p.run_cycle(c)
+h = p.hierarchy()
+print("levels", [m.n_rows for m in h.level_matrices])
+if opts:
+    os.environ["GMG_OPTIONS"] = opts
+c = capi.Context(len(h.level_matrices))
+c.set_tuning(ssor_blocks=blocks)
+c.load_hierarchy(h)
+c.set_smoother(capi.SSOR, 0.5, 1)
+for level in range(1, len(h.level_matrices)):
+    n = h.level_matrices[level].n_rows
+    rng = np.random.default_rng(1)
+    u, r = c.vector(n, np.zeros(n)), c.vector(n, rng.standard_normal(n))
+    c.smoother_step(level, u, r, True); c.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        c.smoother_step(level, u, r, True)
+    c.synchronize()
+    print(f"level {level}: {n} rows, {(time.perf_counter() - t) / reps * 1e3:.3f} ms per application (blocks={blocks})", flush=True)
