@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cycles", type=int, default=5, help="adaptive cycles to run (the reference runs 5); the last one is timed")
     ap.add_argument("--partition-level0", default="auto", choices=["auto", "always", "never"],
                     help="N > 1: row-partition level 0 (coarse CG over RCCL) or keep it replicated; auto decides by size (DESIGN.md 6)")
+    ap.add_argument("--refinement-estimator", default="Kelly", choices=["Kelly", "Kelly + residual"],
+                    help="marking rule: Kelly = the cluster runs (January 2018), Kelly + residual = the reference's HEAD")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8)
     args = ap.parse_args()
@@ -128,7 +130,11 @@ def main():
     p = S.Problem(S.prm_text(left=0, right=w["box"], mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
                              bc="Inhomogeneous", cycles=args.cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True,
                              quad_rhs=1, global_refinement=0, smoother=args.smoother, ssor_blocks=args.ssor_blocks,
-                             partition_level0=args.partition_level0))
+                             partition_level0=args.partition_level0,
+                             # the marking rule of the revision that produced the cluster logs BASELINE.json's configs are
+                             # quoted on: the timed cycle then IS the reference's (64k atoms, cycle 4: 1 926 877 DoFs on
+                             # levels 1 771 561 / 170 516 / 14 336, SSOR_64k_atoms.o876224:50-52); tests/test_cluster_cycles.py
+                             refinement_estimator=args.refinement_estimator))
     p.set_nacl_atoms(w["nacl"])
     if launched:
         # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
@@ -269,6 +275,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["label"] + f", adaptive cycle {args.cycles - 1} of {args.cycles}", "cycle": args.cycles - 1,
+                       "refinement_estimator": args.refinement_estimator + (" (reproduces the reference's cluster logs cycle by cycle: tests/test_cluster_cycles.py)" if args.refinement_estimator == "Kelly" else " (the reference's HEAD)"),
                        "smoother": args.smoother + (f" (0.5, 2 steps), {args.ssor_blocks} block(s)" if args.smoother == "SSOR" else ""),
                        "smoothers": smoothers, "cycles": cycles,
                        "all_cycles_DoF_it_per_s": sum(c["dofs"] * c["outer_cg_iterations"] for c in cycles)

@@ -255,18 +255,17 @@ inline int halo_exchange(Comm &c, const HaloPlan &h, double *x, int64_t n_owned,
   if (c.shm) return shm_halo_exchange(c, h, x, n_owned, stream);
   if (ncclGroupStart() != ncclSuccess) return 1;
   int64_t so = 0, ro = 0;
-  for (int i = 0; i < h.n_neighbors; ++i) {
-    if (h.send_count[(size_t)i] > 0 &&
-        ncclSend(h.send_buf + so, (size_t)h.send_count[(size_t)i], ncclDouble, h.rank[(size_t)i], c.comm, stream) != ncclSuccess)
-      return 1;
-    if (h.recv_count[(size_t)i] > 0 &&
-        ncclRecv(x + n_owned + ro, (size_t)h.recv_count[(size_t)i], ncclDouble, h.rank[(size_t)i], c.comm, stream) != ncclSuccess)
-      return 1;
+  bool failed = false;
+  for (int i = 0; i < h.n_neighbors && !failed; ++i) {
+    if (h.send_count[(size_t)i] > 0)
+      failed = ncclSend(h.send_buf + so, (size_t)h.send_count[(size_t)i], ncclDouble, h.rank[(size_t)i], c.comm, stream) != ncclSuccess;
+    if (!failed && h.recv_count[(size_t)i] > 0)
+      failed = ncclRecv(x + n_owned + ro, (size_t)h.recv_count[(size_t)i], ncclDouble, h.rank[(size_t)i], c.comm, stream) != ncclSuccess;
     so += h.send_count[(size_t)i];
     ro += h.recv_count[(size_t)i];
   }
-  if (ncclGroupEnd() != ncclSuccess) return 1;
-  return 0;
+  if (ncclGroupEnd() != ncclSuccess) return 1;  // always closed, also after a failed send / recv
+  return failed ? 1 : 0;
 }
 
 inline int allreduce_sum(Comm &c, double *dev, int count, hipStream_t stream) {

@@ -122,6 +122,8 @@ struct gmg_context {
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
   bool sgs_disable_wave = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
+  int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
+  int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
   bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false;
   int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
   double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
@@ -158,6 +160,20 @@ namespace {
     int rc_ = (call);             \
     if (rc_ != GMG_OK) return rc_; \
   } while (0)
+
+// a rejected launch (bad grid, too much dynamic LDS, ...) leaves no trace but hipGetLastError: every entry point that
+// enqueued kernels ends with this, so the failure surfaces as GMG_ERR_HIP instead of a silently missing result
+#define RETURN_LAUNCHED(ctx)                                                      \
+  do {                                                                            \
+    const hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                       \
+      (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e_);       \
+      return GMG_ERR_HIP;                                                         \
+    }                                                                             \
+    return GMG_OK;                                                                \
+  } while (0)
+
+int launch_status(gmg_context *ctx) { RETURN_LAUNCHED(ctx); }
 
 int fail(gmg_context *ctx, int code, const char *msg) {
   ctx->err = msg;
@@ -285,7 +301,9 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   m.valid = true;
   phase("csr copy");
   // SELL-64 copy when the rows are regular enough (level-0 lattice, active-mesh matrix)
-  if (n_rows >= 1024 && !ctx->disable_sell) {
+  // the SELL kernels gather through 32-bit byte offsets (c << 3 into a 2 GiB buffer descriptor): columns beyond 2^28
+  // stay on the CSR row-window kernel
+  if (n_rows >= 1024 && !ctx->disable_sell && n_cols < ((int64_t)1 << 28)) {
     const int64_t n_slices = (n_rows + 63) / 64;
     std::vector<int32_t> sp((size_t)n_slices + 1, 0);
     // column patterns: a slice qualifies when all 64 rows exist and the union of (col - row) over
@@ -633,7 +651,7 @@ int spmv(gmg_context *ctx, const DevCSR &m, int mode, const double *x, double *y
     case kAddTo: launch_spmv_mode<kAddTo>(ctx, m, a); break;
     default: return fail(ctx, GMG_ERR_INVALID, "bad spmv mode");
   }
-  return GMG_OK;
+  return launch_status(ctx);
 }
 
 // ---- reductions to the host -------------------------------------------------------------
@@ -655,6 +673,7 @@ int dot_host(gmg_context *ctx, const double *x, const double *y, int64_t n, doub
   if (ctx->comm.n_ranks > 1) {
     if (allreduce_sum(ctx->comm, ctx->scal_dev, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
   }
+  CHK(launch_status(ctx));
   CHK(fetch_scalars(ctx, 1));
   *out = ctx->scal_host[0];
   return GMG_OK;
@@ -712,7 +731,8 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
         ctx->stats.sgs_substeps += L.sgs.w_steps;
         ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
       }
-      launch_timed(ctx, sgs_wave_kernel<false>, dim3(L.sgs.n_blocks), dim3(kSwThreads), (size_t)L.sgs.w_lds_bytes, p);
+      const size_t lds = ctx->sgs_lds_bytes_override > 0 ? (size_t)ctx->sgs_lds_bytes_override : (size_t)L.sgs.w_lds_bytes;
+      launch_timed(ctx, sgs_wave_kernel<false>, dim3(L.sgs.n_blocks), dim3(kSwThreads), lds, p);
     }
     HIPC(hipGetLastError());
     return GMG_OK;
@@ -793,7 +813,7 @@ int smooth_level(gmg_context *ctx, int l, double **u_io, const double *rhs, bool
     }
   }
   *u_io = u;
-  return GMG_OK;
+  return launch_status(ctx);
 }
 
 // Sample i brackets iteration i * prof_every of the solve just finished.  Iterations at or beyond the
@@ -843,6 +863,7 @@ int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
       const int rc = enqueue_one(launched++);
       if (rc != GMG_OK) return rc;
     }
+    CHK(launch_status(ctx));
     HIPC(hipMemcpyAsync(&ctx->st_host[slot], ctx->st, sizeof(CGState), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipEventRecord(ctx->ev_chunk[slot], ctx->stream));
     return GMG_OK;
@@ -1019,7 +1040,7 @@ int vcycle(gmg_context *ctx, double *dst, const double *src) {
     if (e > b) HIPC(hipMemcpyAsync(dst, dst_v + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
   }
   ctx->stats.vcycles++;
-  return GMG_OK;
+  return launch_status(ctx);
 }
 
 // inverse diagonal + Gershgorin bound of D^-1 A (host), upload
@@ -1138,6 +1159,21 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) c += in_dir(i, pcol[(size_t)k]);
         return c;
       };
+      // ---- groups per sub-step for this direction: every step needs ceil(widest row / 8 g) sub-steps, a sub-step of g
+      // groups costs about 3 + g units (measured: ~300 + 100 g cycles); steps are roughly the stages
+      int g_dir = 2;
+      {
+        std::vector<int> stage_len((size_t)n_stages, 0);
+        for (int32_t i : crow) stage_len[(size_t)stage[(size_t)i]] = std::max(stage_len[(size_t)stage[(size_t)i]], n_ent(i));
+        double best = 1e300;
+        for (int gg = 1; gg <= 4; ++gg) {
+          double cost = 0;
+          for (int t = 0; t < n_stages; ++t) cost += (double)std::max(1, (stage_len[(size_t)t] + 8 * gg - 1) / (8 * gg)) * (3.0 + gg);
+          if (cost < best) { best = cost; g_dir = gg; }
+        }
+        if (ctx->sgs_groups > 0) g_dir = std::min(4, ctx->sgs_groups);
+      }
+      const int w_dir = 8 * g_dir, stride = sw_stride(g_dir);
       // ---- steps: <= 64 rows of one stage, records of a sub-step <= kSwMaxBlock bytes, working set <= y_cap
       struct Step { int32_t first, nrows, len; };
       std::vector<int32_t> seq;
@@ -1150,7 +1186,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           const int i = by_stage[(size_t)q];
           const int li = n_ent(i);
           const int nl = std::max(cur.len, li);
-          const int64_t raw = 16 + (int64_t)(cur.nrows + 1) * kSwStride;
+          const int64_t raw = 16 + (int64_t)(cur.nrows + 1) * stride;
           if (cur.nrows > 0 && (cur.nrows == 64 || raw > kSwMaxBlock || (cur.nrows + 1) * (nl + 1) > y_cap)) {
             steps.push_back(cur);
             cur = Step{(int32_t)seq.size(), 0, 0};
@@ -1217,6 +1253,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         R.n_ws = n_slot;
         max_ws = std::max(max_ws, n_slot);
         R.backward = dir;
+        R.groups = g_dir;
         R.n_steps = 0;
         // ---- records in consumption order; a block never straddles the end of the ring
         const int64_t base = ((int64_t)stream.size() + kSwChunk - 1) / kSwChunk * kSwChunk;
@@ -1225,9 +1262,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         for (size_t st = s0; st < s1; ++st) {
           const Step &S = steps[st];
           const int nr = S.nrows;
-          const int n_sub = std::max(1, (S.len + kSwW - 1) / kSwW);
-          const int64_t raw = 16 + (int64_t)nr * kSwStride;
+          const int n_sub = std::max(1, (S.len + w_dir - 1) / w_dir);
+          const int g = g_dir;
           for (int sub = 0; sub < n_sub; ++sub) {
+            const int64_t raw = 16 + (int64_t)nr * stride;
             if (off % kSwRing + raw > kSwRing) off = (off / kSwRing + 1) * kSwRing;
             stream.resize((size_t)(base + off + raw), 0);
             char *blk = stream.data() + base + off;
@@ -1238,7 +1276,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             if (prev_hdr >= 0) {
               SwStepHdr ph;
               std::memcpy(&ph, stream.data() + base + prev_hdr, sizeof ph);
-              ph.advance = (uint32_t)(off - prev_hdr); ph.next_raw = (uint32_t)raw; ph.next_nrows = (uint32_t)nr;
+              ph.advance = (uint32_t)(off - prev_hdr); ph.next_raw = (uint32_t)raw; ph.next_nrows = (uint16_t)nr;
               std::memcpy(stream.data() + base + prev_hdr, &ph, sizeof ph);
             } else {
               R.first_raw = (int32_t)raw; R.first_nrows = nr;
@@ -1247,8 +1285,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             for (int u = 0; u < nr; ++u) {
               const int i = seq[(size_t)(S.first + u)];
               const int32_t ci = row_ci[(size_t)(rb + i)];
-              char *rec = blk + 16 + (size_t)u * kSwStride;
-              const int64_t rec_pos = base + off + 16 + (int64_t)u * kSwStride;
+              char *rec = blk + 16 + (size_t)u * stride;
+              const int64_t rec_pos = base + off + 16 + (int64_t)u * stride;
               if (sub == n_sub - 1) (dir == 0 ? rpos_f : rpos_b)[(size_t)ci] = (int32_t)(rec_pos / 8);  // the rhs is read when the row is finished
               if (dir == 1 && sub == 0) prefix_pos[(size_t)i] = (int32_t)(rec_pos / 8 + 2);             // the prefix when it is started
               double *f = reinterpret_cast<double *>(rec);
@@ -1257,16 +1295,16 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               f[0] = 0.0; f[1] = invd[(size_t)i]; f[2] = 0.0;
               w[6] = my;
               w[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
-              uint32_t *ad = reinterpret_cast<uint32_t *>(rec + 32 + 8 * kSwW);
+              uint32_t *ad = reinterpret_cast<uint32_t *>(rec + 32 + 64 * g);
               int e = 0, seen = 0;
-              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1] && e < kSwW; ++k) {
+              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1] && e < 8 * g; ++k) {
                 const int c = pcol[(size_t)k];
                 if (!in_dir(i, c)) continue;
-                if (seen++ < sub * kSwW) continue;  // entries of earlier sub-steps
+                if (seen++ < sub * w_dir) continue;  // entries of earlier sub-steps
                 f[4 + e] = pval[(size_t)k];
                 ad[e++] = (uint32_t)slot_of[(size_t)c] * 8u;
               }
-              for (; e < kSwW; ++e) { f[4 + e] = 0.0; ad[e] = my; }
+              for (; e < 8 * g; ++e) { f[4 + e] = 0.0; ad[e] = my; }
             }
             off += raw;
             R.n_steps++;
@@ -1308,7 +1346,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   HIPC(hipMalloc(&G.w_ycur, sizeof(double) * std::max<size_t>(ci_row.size(), 1)));
   HIPC(hipStreamSynchronize(ctx->stream));
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = y_slots * 8 + kSwRing + 16;
+  G.w_lds_bytes = y_slots * 8 + kSwRing + 16 + kSwSlack;
   G.w_n_ranges = (int)ranges.size();
   G.w_n_coupled = (int64_t)ci_row.size();
   G.w_stream_bytes = (int64_t)stream.size();
@@ -1666,17 +1704,17 @@ int gmg_vec_set_zero(gmg_context *ctx, double *x, int64_t n) {
 int gmg_vec_equ(gmg_context *ctx, double *y, double a, const double *x, int64_t n) {
   if (!ctx || n < 0) return GMG_ERR_INVALID;
   if (n) hipLaunchKernelGGL(vec_equ_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, y, a, x, n);
-  return GMG_OK;
+  RETURN_LAUNCHED(ctx);
 }
 int gmg_vec_add(gmg_context *ctx, double *y, double a, const double *x, int64_t n) {
   if (!ctx || n < 0) return GMG_ERR_INVALID;
   if (n) hipLaunchKernelGGL(vec_add_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, y, a, x, n);
-  return GMG_OK;
+  RETURN_LAUNCHED(ctx);
 }
 int gmg_vec_sadd(gmg_context *ctx, double *y, double s, double a, const double *x, int64_t n) {
   if (!ctx || n < 0) return GMG_ERR_INVALID;
   if (n) hipLaunchKernelGGL(vec_sadd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, y, s, a, x, n);
-  return GMG_OK;
+  RETURN_LAUNCHED(ctx);
 }
 int gmg_vec_dot(gmg_context *ctx, const double *x, const double *y, int64_t n, double *out) {
   if (!ctx || !out || n < 0) return GMG_ERR_INVALID;
@@ -1693,6 +1731,7 @@ int gmg_vec_norms(gmg_context *ctx, const double *x, int64_t n, double *l1, doub
     if (allreduce_max(ctx->comm, ctx->scal_dev + 2, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
     if (allreduce_sum(ctx->comm, ctx->scal_dev + 3, 1, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-reduce failed");
   }
+  CHK(launch_status(ctx));
   CHK(fetch_scalars(ctx, 4));
   if (l1) *l1 = ctx->scal_host[0];
   if (l2) *l2 = std::sqrt(ctx->scal_host[1]);
@@ -1732,7 +1771,7 @@ int gmg_precondition_jacobi(gmg_context *ctx, double omega, double *dst, const d
   if (!ctx || !ctx->S.valid) return GMG_ERR_INVALID;
   hipLaunchKernelGGL(vec_scale_mul_kernel, dim3(grid_for(ctx->S.n_rows)), dim3(kThreads), 0, ctx->stream, dst, omega, src,
                      (const double *)ctx->S_invd, ctx->S.n_rows);
-  return GMG_OK;
+  RETURN_LAUNCHED(ctx);
 }
 
 int gmg_coarse_solve(gmg_context *ctx, double *dst, const double *src, int *iterations, double *residual) {
@@ -1919,7 +1958,8 @@ int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo,
   a.cutoff = cutoff; a.r_c = r_c; a.use_lists = use_lists;
   a.qp = d_qp; a.nq = nq; a.n_cells = (int)n_cells; a.dens = d_dens;
   hipLaunchKernelGGL(charge_density_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(kThreads), 0, ctx->stream, a);
-  hipError_t e = hipMemcpyAsync(dens, d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(dens, d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   cleanup();
   if (e != hipSuccess) { ctx->err = std::string("gmg_charge_density: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
@@ -2061,6 +2101,8 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "coarse_chunk") ctx->coarse_chunk = (int)value;
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
+  else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
+  else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
   else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }
   else return fail(ctx, GMG_ERR_INVALID, "gmg_set_option: unknown key");
   return GMG_OK;

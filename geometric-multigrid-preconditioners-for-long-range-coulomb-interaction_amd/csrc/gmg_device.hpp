@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sell_kernel(SellArgs sa) {
       ++q;
       while (q == qe && s < s1) finish_slice();
     };
-    load_quad(va, ca, q);
+    if (q < Q1) load_quad(va, ca, q);  // (a range of empty slices streams nothing)
     if (q + 1 < Q1) load_quad(vb, cb, q + 1);
     while (q == qe && s < s1) finish_slice();  // (empty slices cannot occur: every row has a diagonal)
     while (q < Q1) {

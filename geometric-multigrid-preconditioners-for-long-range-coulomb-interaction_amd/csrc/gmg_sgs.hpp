@@ -35,9 +35,10 @@ namespace gmg {
 
 constexpr int kSwRing = 32768;     // bytes of the record ring in LDS
 constexpr int kSwChunk = 4096;     // unit the helper waves copy
-constexpr int kSwW = 16;           // entries per sub-step: a row's sum is formed kSwW products at a time
+constexpr int kSwW = 32;           // most entries per sub-step: a row's sum is formed in groups of 8 products, 1..4 groups per sub-step
 constexpr int kSwMaxBlock = 8192;  // bytes of one step's records: 3 blocks + 1 chunk fit the ring (no deadlock)
-constexpr int kSwYSlots = 15872;   // doubles of y in LDS (124 KB) by default
+constexpr int kSwSlack = 0;
+constexpr int kSwYSlots = 15744;   // doubles of y in LDS (123 KB) by default
 constexpr int kSwThreads = 256;    // wave 0 computes, waves 1..3 stream
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.
@@ -49,13 +50,16 @@ struct SwRange {
   int32_t n_own;         // slots [0, n_own): rows updated in this range (written back at its end)
   int32_t n_ws;          // slots in use: updated rows + rows only read
   int32_t backward;      // 1: second sweep, its results are final
-  int32_t first_raw, first_nrows, pad0, pad1;
+  int32_t first_raw, first_nrows, groups, pad1;  // groups: g of every sub-step of the range
 };
 
 
-// A step (<= 64 rows of one stage, lane = row) is cut into SUB-STEPS of exactly kSwW entries per row: the partial
-// sum stays in a register from one sub-step to the next, the last sub-step of a step finishes the rows.  One body
-// of straight-line code serves every row width -- no dispatch on the width, no register sets to merge.
+// A step (<= 64 rows of one stage, lane = row) is cut into SUB-STEPS of exactly 8 g entries per row; g (1..4 groups of
+// 8) is fixed for a whole range of steps, chosen by the host so that nearly every step is one sub-step (a 27-point
+// level operator: g = 2 forward, 3 backward).  The sweep of a range is therefore ONE straight-line loop body --
+// gathers, values, the chain of 8 g multiply-adds -- with a single taken branch per sub-step (a lone wave pays a
+// refetch for every taken branch: dispatching on the width per sub-step doubled the time of the sweep); the partial
+// sum stays in a register from one sub-step to the next and the last sub-step of a step finishes the rows.
 // Records of one sub-step: a 16-byte header, then one record per row (lane-major, so that every field is read with
 // an immediate offset from the lane's base address, two or four values per LDS instruction):
 //   +0  double r        (rewritten by the pre-pass; read by the last sub-step)      +8  double 1 / a_ii
@@ -63,17 +67,16 @@ struct SwRange {
 //                        forward sweep's last sub-step)
 //   +24 uint32 LDS byte address of the row's own y slot
 //   +28 uint32 aux      (forward: index, in doubles, of the row's prefix field in the backward records)
-//   +32 double a[kSwW]  then uint32 LDS byte address of the column's y slot [kSwW]
-// rows are padded with a = +0.0, column = the row itself; the record stride is 32 + 12 kSwW rounded up to an odd
-// multiple of 16 bytes (16-byte LDS reads of consecutive lanes then hit distinct banks).
+//   +32 double a[8 g]   then uint32 LDS byte address of the column's y slot [8 g]
+// rows are padded with a = +0.0, column = the row itself; the record stride is 32 + 96 g rounded up to an odd
+// multiple of 16 bytes = 96 g + 48 (16-byte LDS reads of consecutive lanes then hit distinct banks).
 struct SwStepHdr {
-  uint16_t nrows, flags;  // flags: 1 = first sub-step of its step, 2 = last one
-  uint32_t next_nrows;
-  uint32_t advance;       // bytes to the next header (>= the raw size: records never straddle the ring end)
-  uint32_t next_raw;      // raw bytes of the next sub-step's records (0: last of the range)
+  uint16_t nrows, flags;       // flags: 1 = first sub-step of its step, 2 = last one
+  uint16_t next_nrows, pad;
+  uint32_t advance;            // bytes to the next header (>= the raw size: records never straddle the ring end)
+  uint32_t next_raw;           // raw bytes of the next sub-step's records (0: last of the range)
 };
-constexpr int kSwStride = 16 * ((2 + 3 * (kSwW / 4)) | 1);
-static_assert(kSwW % 4 == 0 && 16 + 64 * kSwStride > kSwMaxBlock, "rows per sub-step are limited by kSwMaxBlock");
+__host__ __device__ constexpr int sw_stride(int g) { return 96 * g + 48; }
 
 struct SgsWaveArgs {
   const SwRange *ranges;
@@ -141,10 +144,12 @@ __device__ __forceinline__ void st_rlx(uint32_t addr, uint32_t v) {
   __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// what the compute wave keeps in registers of the sub-step AFTER the one it is computing: the LDS addresses of
-// the columns and the prefix sum, so that the y gathers never wait for a ring read
+// what the compute wave holds in registers of the sub-step AFTER the one it is computing: the LDS addresses of the
+// columns and the prefix sum, so that the y gathers never wait for a ring read.  Always a fresh value (entries beyond
+// the sub-step's groups stay undefined): nothing has to be merged or copied between the register sets.
+template <int G>
 struct NextCols {
-  uint32_t addr[kSwW];
+  uint32_t addr[8 * G];
   uint32_t my, aux;
   double prefix;
   u32x4 hdr;  // SwStepHdr as loaded
@@ -152,24 +157,29 @@ struct NextCols {
 
 // Lanes beyond the sub-step's rows run on the last row's record (all reads stay in range, control flow stays
 // wave-uniform); only the stores that finish a row are masked.
-__device__ __forceinline__ void load_next(NextCols &N, uint32_t blk, int nrows, int lane) {
+// Lanes beyond the sub-step's rows run on the last row's record (all reads stay in range, control flow stays
+// wave-uniform); only the stores that finish a row are masked.
+template <int G>
+__device__ __forceinline__ NextCols<G> load_next(uint32_t blk, int nrows, int lane) {
+  NextCols<G> N;
   N.hdr = lds_ld<u32x4>(blk);
-  const uint32_t rec = blk + 16 + (uint32_t)min(lane, nrows - 1) * (uint32_t)kSwStride;
+  const uint32_t rec = blk + 16 + (uint32_t)min(lane, nrows - 1) * (uint32_t)sw_stride(G);
   const u32x4 q = lds_ld<u32x4>(rec + 16);
   N.prefix = __hiloint2double((int)q.y, (int)q.x);
   N.my = q.z; N.aux = q.w;
 #pragma unroll
-  for (int j = 0; j < kSwW / 4; ++j) {
-    const u32x4 c = lds_ld<u32x4>(rec + 32 + 8 * kSwW + 16 * j);
+  for (int j = 0; j < 2 * G; ++j) {
+    const u32x4 c = lds_ld<u32x4>(rec + 32 + 64 * G + 16 * j);
     N.addr[4 * j] = c.x; N.addr[4 * j + 1] = c.y; N.addr[4 * j + 2] = c.z; N.addr[4 * j + 3] = c.w;
   }
+  return N;
 }
 
 // The sweep of one range by the compute wave.  ring0 / ctr0: LDS addresses of the record ring and of the four counters
 // ([0..2] chunks copied by helper 0..2, [3] bytes consumed).
 // Forward: acc = sum over the columns j < i, kept for the backward sweep; y_i = 0 + (omega (r_i - acc)) / a_ii.
 // Backward: acc = that sum, continued over the columns j >= i; y_i += (omega (r_i - acc)) / a_ii.
-template <bool FWD, bool PROFILE>
+template <int G, bool FWD, bool PROFILE>
 __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, uint32_t ctr0, int lane, double omega, double *stream_d,
                                             unsigned long long &t_wait, int mode) {
   uint32_t pos = 0, avail = 0;
@@ -187,63 +197,71 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
   };
   int nrows = R.first_nrows;
   double carry = 0.0;
-  // two register sets, used alternately: the columns of the sub-step being computed / of the one after it
-  auto one_step = [&](const NextCols &cur, NextCols &nxt) {
+  // one sub-step on the register set `cur`; fills `nxt` with the set of the sub-step after it (two sets used alternately:
+  // no register copies between sub-steps)
+  auto one_step = [&](const NextCols<G> &cur, NextCols<G> &nxt) {
     const uint32_t blk = ring0 + (pos & (uint32_t)(kSwRing - 1));
+    // header: {nrows | flags << 16, next_nrows, advance, next_raw}
     const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hdr.x) >> 16;
-    const int n_nrows = __builtin_amdgcn_readfirstlane((int)cur.hdr.y);
+    const int n_nrows = __builtin_amdgcn_readfirstlane((int)cur.hdr.y) & 0xffff;
     const uint32_t advance = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hdr.z);
     const uint32_t next_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hdr.w);
-    const uint32_t rec = blk + 16 + (uint32_t)min(lane, nrows - 1) * (uint32_t)kSwStride;
-    if (PROFILE && mode == 5) {
+    const uint32_t rec = blk + 16 + (uint32_t)min(lane, nrows - 1) * (uint32_t)sw_stride(G);
+    if (!(PROFILE && mode == 5)) {
+      // ---- every LDS read of the sub-step goes out first: y gathers, own y, values, rhs; then the next sub-step's columns
+      double yv[8 * G], av[8 * G];
+#pragma unroll
+      for (int k = 0; k < 8 * G; ++k) yv[k] = lds_ld<double>(cur.addr[k]);
+      double yold = 0.0;
+      if constexpr (!FWD) yold = lds_ld<double>(cur.my);
+#pragma unroll
+      for (int j = 0; j < 4 * G; ++j) {
+        const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
+        av[2 * j] = a2.x; av[2 * j + 1] = a2.y;
+      }
+      const f64x2 ri = lds_ld<f64x2>(rec);  // r, 1 / a_ii
+      // everything in front of this sub-step's records may be overwritten (relaxed: the LDS queue of this wave is in
+      // order, the store cannot overtake the reads issued before it)
       st_rlx(ctr0 + 12, pos);
-      if (next_raw) { wait_for(pos + advance + next_raw); load_next(nxt, ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane); }
-      pos += advance; nrows = n_nrows;
-      return;
-    }
-    // ---- every LDS read of the sub-step goes out first: y gathers, own y, values, rhs; then the next sub-step's columns
-    double yv[kSwW], av[kSwW];
+      if (next_raw) {
+        wait_for(pos + advance + next_raw);
+        nxt = load_next<G>(ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- the dependent chain, in CSR order
+      double acc = (flags & 1u) ? (FWD ? 0.0 : cur.prefix) : carry;
+      if (!PROFILE || mode != 1) {
 #pragma unroll
-    for (int k = 0; k < kSwW; ++k) yv[k] = lds_ld<double>(cur.addr[k]);
-    const double yold = lds_ld<double>(cur.my);
-#pragma unroll
-    for (int j = 0; j < kSwW / 2; ++j) {
-      const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
-      av[2 * j] = a2.x; av[2 * j + 1] = a2.y;
-    }
-    const f64x2 ri = lds_ld<f64x2>(rec);  // r, 1 / a_ii
-    // everything in front of this sub-step's records may be overwritten (relaxed: the LDS queue of this wave is in
-    // order, the store cannot overtake the reads issued before it)
-    st_rlx(ctr0 + 12, pos);
-    if (next_raw) {
-      wait_for(pos + advance + next_raw);
-      load_next(nxt, ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- the dependent chain, in CSR order
-    double acc = (flags & 1u) ? (FWD ? 0.0 : cur.prefix) : carry;
-    if (!PROFILE || mode != 1) {
-#pragma unroll
-      for (int k = 0; k < kSwW; ++k) acc += av[k] * yv[k];
-    }
-    carry = acc;
-    if ((flags & 2u) && lane < nrows) {
-      if constexpr (FWD) {
-        stream_d[cur.aux] = acc;
-        lds_st<double>(cur.my, 0.0 + (omega * (ri.x - acc)) * ri.y);
-      } else {
+        for (int k = 0; k < 8 * G; ++k) acc += av[k] * yv[k];
+      }
+      carry = acc;
+      if ((flags & 2u) && lane < nrows) {
+        if constexpr (FWD) stream_d[cur.aux] = acc;
         lds_st<double>(cur.my, yold + (omega * (ri.x - acc)) * ri.y);
       }
+    } else {
+      st_rlx(ctr0 + 12, pos);
+      if (next_raw) { wait_for(pos + advance + next_raw); nxt = load_next<G>(ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane); }
     }
     pos += advance;
     nrows = n_nrows;
   };
-  NextCols C0, C1;
   wait_for((uint32_t)R.first_raw);
-  load_next(C0, ring0, nrows, lane);
+  NextCols<G> C0 = load_next<G>(ring0, nrows, lane), C1 = C0;
   for (int s = 0; s < R.n_steps; s += 2) {
     one_step(C0, C1);
     if (s + 1 < R.n_steps) one_step(C1, C0);
+  }
+}
+
+template <bool FWD, bool PROFILE>
+__device__ __forceinline__ void sweep_dispatch(const SwRange &R, uint32_t ring0, uint32_t ctr0, int lane, double omega, double *stream_d,
+                                               unsigned long long &t_wait, int mode) {
+  switch (R.groups) {
+    case 1: sweep_range<1, FWD, PROFILE>(R, ring0, ctr0, lane, omega, stream_d, t_wait, mode); break;
+    case 2: sweep_range<2, FWD, PROFILE>(R, ring0, ctr0, lane, omega, stream_d, t_wait, mode); break;
+    case 3: sweep_range<3, FWD, PROFILE>(R, ring0, ctr0, lane, omega, stream_d, t_wait, mode); break;
+    default: sweep_range<4, FWD, PROFILE>(R, ring0, ctr0, lane, omega, stream_d, t_wait, mode); break;
   }
 }
 
@@ -279,8 +297,8 @@ __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
     if (wid == 0) {
       // ---------------- compute wave
       double *stream_d = reinterpret_cast<double *>(a.stream);
-      if (R.backward) sw::sweep_range<false, PROFILE>(R, ring0, ctr0, lane, a.omega, stream_d, t_wait, a.prof_mode);
-      else sw::sweep_range<true, PROFILE>(R, ring0, ctr0, lane, a.omega, stream_d, t_wait, a.prof_mode);
+      if (R.backward) sw::sweep_dispatch<false, PROFILE>(R, ring0, ctr0, lane, a.omega, stream_d, t_wait, a.prof_mode);
+      else sw::sweep_dispatch<true, PROFILE>(R, ring0, ctr0, lane, a.omega, stream_d, t_wait, a.prof_mode);
     } else {
       // ---------------- helper waves: stream -> ring, one 4 KB chunk at a time, chunk q by helper q % 3
       const int hw = wid - 1;

@@ -105,6 +105,29 @@ int step50_run_cycle(step50_problem *h, int cycle, int on_device) {
 int step50_solve_again(step50_problem *h) {
   return guarded(h, [&] { return DISPATCH(h, solve_again()); });
 }
+// marking-rule study (tools/marking_rule_scan.py): per active cell of the cycle just estimated, the Kelly face sum
+// eta_K^2, the residual term h_K^2 int_K (4 pi rho)^2, the cell's level, and its centre
+int64_t step50_n_active_cells(step50_problem *h) { return (int64_t)DISPATCH(h, estimator_kelly_sq).size(); }
+int step50_estimator_components(step50_problem *h, double *kelly_sq, double *residual_sq, int32_t *level, double *centre) {
+  return guarded(h, [&] {
+    const auto &k = DISPATCH(h, estimator_kelly_sq);
+    const auto &r = DISPATCH(h, estimator_residual_sq);
+    std::memcpy(kelly_sq, k.data(), sizeof(double) * k.size());
+    std::memcpy(residual_sq, r.data(), sizeof(double) * r.size());
+    auto fill = [&](auto &P) {
+      for (size_t a = 0; a < P.active_cells.size(); ++a) {
+        const auto &ac = P.active_cells[a];
+        level[a] = ac.level;
+        double x0[3] = {0, 0, 0};
+        const double hh = P.triangulation.cell_size(ac.level);
+        P.triangulation.cell_origin(ac.level, P.triangulation.levels[(size_t)ac.level][(size_t)ac.index], x0);
+        for (int d = 0; d < 3; ++d) centre[3 * a + d] = x0[d] + 0.5 * hh;
+      }
+    };
+    if (h->dim == 2) fill(*h->p2); else fill(*h->p3);
+    return 0;
+  });
+}
 // bench: re-upload the current cycle's operators with another smoother
 int step50_set_smoother(step50_problem *h, const char *smoother, int ssor_blocks) {
   return guarded(h, [&] { return DISPATCH(h, set_smoother(std::string(smoother), ssor_blocks)); });

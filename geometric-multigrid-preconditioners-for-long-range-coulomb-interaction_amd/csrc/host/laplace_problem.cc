@@ -203,7 +203,10 @@ void ParameterReader::declare_parameters() {
             // additions of this build (the reference selects the smoother by editing :969-970)
             {"Smoother", "SSOR"}, {"Smoother damping", "0.5"}, {"Smoother steps", "2"}, {"Chebyshev degree", "2"},
             {"Device resident outer CG", "false"}, {"SSOR blocks", "1"}, {"Charge densities on device", "true"},
-            {"Partition level 0", "auto"}};
+            {"Partition level 0", "auto"},
+            // HEAD marks with Kelly + the cell residual (:1040-1089); the cluster logs (January 2018) are reproduced by
+            // the Kelly indicator alone (tools/marking_rule_scan.py)
+            {"Refinement estimator", "Kelly + residual"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -266,6 +269,9 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.ssor_blocks = (int)prm.get_integer("SSOR blocks");
   p.densities_on_device = prm.get_bool("Charge densities on device");
   p.partition_level0 = prm.get("Partition level 0");
+  p.refinement_estimator = prm.get("Refinement estimator");
+  if (p.refinement_estimator != "Kelly + residual" && p.refinement_estimator != "Kelly")
+    throw std::runtime_error("Refinement estimator must be <Kelly + residual> or <Kelly>");
   return p;
 }
 

@@ -64,6 +64,7 @@ struct Parameters {
   int ssor_blocks = 1;  // 1: exact sequential SGS (mpirun=1); B: rank-local SGS on B blocks (mpirun=B)
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
+  std::string refinement_estimator = "Kelly + residual";  // HEAD (:1040-1089) | "Kelly": the indicator of the older cluster runs
   static Parameters from(const ParameterReader &prm);
 };
 
@@ -156,6 +157,7 @@ class LaplaceProblem {
   std::vector<std::vector<char>> level_boundary, level_refinement_edge;  // MGConstrainedDoFs
   std::vector<std::vector<double>> density_values_for_each_cell;         // [active cell][q]
   std::vector<float> error_per_cell;
+  std::vector<double> estimator_kelly_sq, estimator_residual_sq;  // per active cell: face-jump sum / h_K^2 int (4 pi rho)^2 (kept for the marking-rule study)
   std::vector<std::vector<char>> refine_flags;
 
   void pcout(const std::string &s);

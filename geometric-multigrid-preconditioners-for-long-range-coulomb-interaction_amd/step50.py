@@ -76,6 +76,7 @@ def prm_text(**kw) -> str:
         "ssor_blocks": ("Solver input data", "SSOR blocks"),
         "densities_on_device": ("Misc", "Charge densities on device"),
         "partition_level0": ("Solver input data", "Partition level 0"),
+        "refinement_estimator": ("Misc", "Refinement estimator"),
     }
     sections = {}
     for k, v in kw.items():
@@ -142,6 +143,15 @@ class Problem:
     def solve_again(self):
         self._chk(self.L.step50_solve_again(self.h), "solve")
         return self.report(-1)
+
+    def estimator_components(self):
+        """Per active cell of the cycle just estimated: (Kelly face sum eta_K^2, residual term, level, centre)."""
+        self.L.step50_n_active_cells.restype = C.c_int64
+        n = self.L.step50_n_active_cells(self.h)
+        k, r, lv, ctr = np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int32), np.zeros((n, 3))
+        self._chk(self.L.step50_estimator_components(self.h, k.ctypes.data_as(C.POINTER(C.c_double)), r.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     lv.ctypes.data_as(C.POINTER(C.c_int32)), ctr.ctypes.data_as(C.POINTER(C.c_double))), "estimator_components")
+        return k, r, lv, ctr
 
     def set_smoother(self, smoother: str, ssor_blocks: int = 1):
         """Another smoother on the operators of the cycle just run (re-uploads them; the next solve_again uses it)."""

@@ -199,7 +199,8 @@ int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant);
 /* Diagnostic / measurement options by name (defaults are the production paths).  Keys: host_threads,
  * debug_upload, disable_sell, disable_patterns, disable_compression, disable_sellp, sell_grid, sellp_cost,
  * cg_variant, coarse_chunk, sgs_y_slots (doubles of LDS the SSOR sweep may use for y: small values force
- * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep).  Options that shape a device
+ * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep), sgs_profile (instrumented sweep),
+ * sgs_lds_bytes_override (tests: a value over the CU's 160 KB makes the sweep's launch fail -> GMG_ERR_HIP).  Options that shape a device
  * layout take effect at the next gmg_set_*_matrix.  The same keys are read once from the environment
  * variable GMG_OPTIONS="key=value,..." at gmg_create (for profiling scripts around bench.py).        */
 int gmg_set_option(gmg_context *ctx, const char *key, double value);

@@ -1,0 +1,86 @@
+"""Adaptive cycles >= 1 of the BASELINE configs against the reference's cluster logs
+(Cluster runs output and postprocessing/SSOR_run.o876223, SSOR_64k_atoms.o876224; January 2018, 20 MPI ranks).
+
+Those logs predate HEAD's estimator: they are reproduced -- cells, DoFs by level, starting values to every printed
+digit, solution norms to 9 digits -- by the Kelly indicator alone (prm "Refinement estimator = Kelly"), i.e. HEAD's
+estimate_error_and_mark_cells (src/step-50.cc:1040-1089) without the cell-residual term it adds at :1055-1082
+(tools/marking_rule_scan.py is the study that found this).  What the logs cannot pin on one rank is the CG iteration
+count: they ran SSOR on 20 ranks (block Jacobi of rank-local sweeps over p4est's partition), so counts may differ by
+one; the exact count is pinned against the oracle on the same hierarchy.
+
+CPU: host-side C++ mesh / assembly / estimator + oracle solver.  GPU (-m gpu): the same cycles with the HIP solve."""
+import numpy as np
+import pytest
+
+from conftest import rel_close
+from gpu_util import pkg
+from oracle import gmg_oracle as go
+
+
+def cluster_run(golden, n_atoms):
+    for key in ("cluster/SSOR_run", "cluster/SSOR_64k_atoms"):
+        for run in golden[key]["runs"]:
+            if run.get("n_atoms") == n_atoms:
+                return run["cycles"]
+    raise KeyError(n_atoms)
+
+
+def problem(nacl, cycles, smoother="SSOR"):
+    S = pkg().step50
+    p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+                             cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0,
+                             smoother=smoother, refinement_estimator="Kelly"))
+    p.set_nacl_atoms(nacl)
+    return p
+
+
+def check_against_log(rep, g, cycle):
+    assert rep["active_cells"] == g["active_cells"], cycle
+    assert rep["dofs_by_level"] == g["dofs_by_level"], cycle
+    # starting value = |b - A x0| with x0 interpolated from the previous solve: pins mesh, assembly, rhs and the transfer
+    # (cycle 0 is printed with 6 digits, later cycles with 10; the 20-rank solves stop at slightly different iterates: 5e-10)
+    assert abs(rep["starting_value"] - g["starting_value"]) <= (0.6e-6 if cycle == 0 else 5e-10), (cycle, rep["starting_value"], g["starting_value"])
+    assert abs(rep["cg_iterations"] - g["cg_iterations"]) <= 1, (cycle, rep["cg_iterations"], g["cg_iterations"])
+    for k in ("sol_l1", "sol_l2", "sol_linf"):
+        assert rel_close(rep[k], g[k], 8), (cycle, k, rep[k], g[k])
+
+
+def test_eight_atoms_five_cycles_host_plus_oracle(golden):
+    """BASELINE config 2 (atom_n1_8): SSOR_run.o876223:14-58."""
+    G = cluster_run(golden, 8)
+    p = problem(1, 5)
+    go.set_threads(4)
+    for cycle in range(5):
+        p.run_cycle(cycle, on_device=False)
+        h = p.hierarchy()
+        r = go.OracleMG(h, smoother=go.SSOR).solve(h.system_rhs, x0=p.vector("initial_guess"))
+        assert r["status"] == go.OK
+        x = r["x"]
+        rep = p.finish_cycle_with(x)
+        rep.update(cg_iterations=r["iterations"], starting_value=r["starting_value"], sol_l1=float(np.abs(x).sum()),
+                   sol_l2=float(np.sqrt(x @ x)), sol_linf=float(np.abs(x).max()))
+        check_against_log(rep, G[cycle], cycle)
+    assert rep["dofs_by_level"] == [91125, 8929, 12680]
+    go.set_threads(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nacl,n_atoms,counts", [(1, 8, [1, 6, 7, 6, 8]), (5, 1000, [1, 6, 7, 8, 8]), (10, 8000, None), (20, 64000, [1, 5, 7, 7, 7])])
+def test_cluster_cycles_on_mi355x(golden, nacl, n_atoms, counts):
+    """BASELINE configs 2-5 through all five cycles of the cluster runs, SSOR smoother, solve on the GPU; the
+    iteration counts are the oracle's on one rank (configs 2 / 3 / 5: recorded from CPU runs of the oracle; config 4:
+    checked live on the last cycle)."""
+    G = cluster_run(golden, n_atoms)
+    p = problem(nacl, 5)
+    for cycle in range(5):
+        rep = p.run_cycle(cycle, on_device=True)
+        check_against_log(rep, G[cycle], cycle)
+        if counts:
+            assert rep["cg_iterations"] == counts[cycle], (cycle, rep["cg_iterations"])
+    if counts is None:
+        h = p.hierarchy()
+        go.set_threads(16)
+        ref = go.OracleMG(h, smoother=go.SSOR).solve(h.system_rhs, x0=p.vector("initial_guess"))
+        go.set_threads(1)
+        assert rep["cg_iterations"] == ref["iterations"] and rep["coarse_iterations"] == ref["coarse_iterations"]
+    p.close()

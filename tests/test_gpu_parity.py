@@ -264,3 +264,22 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     exact = go.OracleMG(hier3, smoother=go.SSOR).smooth(level, u0, rhs, True)
     assert (blocks == 1) == np.array_equal(exact, mg.smooth(level, u0, rhs, True))  # the blocks really decouple
     c.close()
+
+
+def test_rejected_launch_is_reported(hier3):
+    """A kernel launch the runtime rejects (here: the SSOR sweep asked for more dynamic LDS than a CU has) must come
+    back as ERR_HIP from the entry point that enqueued it, not as a silently missing result."""
+    c = capi().Context(len(hier3.level_matrices))
+    c.load_hierarchy(hier3)
+    c.set_smoother(capi().SSOR, 0.5, 2)
+    n = hier3.level_matrices[3].n_rows
+    u, r = c.vector(n, np.zeros(n)), c.vector(n, np.ones(n))
+    c.smoother_step(3, u, r, True)  # fine
+    c.set_option("sgs_lds_bytes_override", 400 * 1024)
+    with pytest.raises(capi().GMGError) as exc:
+        c.smoother_step(3, u, r, True)
+    assert exc.value.code == capi().ERR_HIP
+    c.set_option("sgs_lds_bytes_override", 0)
+    c.smoother_step(3, u, r, True)  # the context stays usable
+    assert np.isfinite(u.download()).all()
+    c.close()

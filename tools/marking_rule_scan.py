@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Marking-rule study: which estimator / threshold reproduces the refinement the reference's
+cluster logs show at cycle 1?  CPU only (host C++ mesh + assembly + estimator, oracle solve).
+
+Targets, cycle 0 -> cycle 1 (Cluster runs output and postprocessing/SSOR_run.o876223:23-31, SSOR_64k_atoms.o876224:23-31):
+  8 atoms   85184 -> 85744 cells (80 cells refined), level 1: 1260 DoFs, starting value 0.1205202179
+  64k atoms 1728000 -> 1728560 cells (80 cells refined), level 1: 1368 DoFs
+HEAD's rule (src/step-50.cc:1040-1089: Kelly with Strategy::cell_diameter + h_K^2 |4 pi rho|^2, threshold 0.6 max)
+refines 32 / 56 cells.  The script evaluates variants of the estimator on the cycle-0 solution and prints how many
+cells each one marks."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("geometric-multigrid-preconditioners-for-long-range-coulomb-interaction_amd")
+from oracle import gmg_oracle as go
+S = pkg.step50
+nacl = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+go.set_threads(8)
+p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+                         cycles=2, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="SSOR"))
+p.set_nacl_atoms(nacl)
+p.run_cycle(0, on_device=False)
+h = p.hierarchy()
+r = go.OracleMG(h, smoother=go.SSOR).solve(h.system_rhs, x0=p.vector("initial_guess"))
+rep = p.finish_cycle_with(r["x"])
+k2, r2, lv, ctr = p.estimator_components()
+print(f"{8 * nacl ** 3} atoms: {len(k2)} cells, HEAD threshold {rep['refine_threshold']:.6e}")
+PI4 = 4 * np.pi
+variants = {
+    "kelly(cell_diameter) + residual  [HEAD]": np.sqrt(k2 + r2),
+    "kelly(cell_diameter) only": np.sqrt(k2),
+    "kelly(cell_diameter_over_24) only": np.sqrt(k2 / 24),
+    "kelly(cell_diameter_over_24) + residual": np.sqrt(k2 / 24 + r2),
+    "kelly(cell_diameter) + residual without the second 4 pi": np.sqrt(k2 + r2 / PI4 ** 2),
+    "kelly(cell_diameter_over_24) + residual without the second 4 pi": np.sqrt(k2 / 24 + r2 / PI4 ** 2),
+    "kelly(cell_diameter) + residual with h_K (not h_K^2)": np.sqrt(k2 + r2 / (0.25 * np.sqrt(3))),
+    "residual only": np.sqrt(r2),
+}
+print(f"{'estimator':70s} " + " ".join(f"{f:>6.2f}" for f in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2, 0.1)) + "   factor hitting 80 cells")
+for name, eta in variants.items():
+    eta = eta.astype(np.float32)
+    mx = eta.max()
+    counts = [int((eta >= np.float32(f) * mx).sum()) for f in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2, 0.1)]
+    srt = np.sort(eta)[::-1]
+    # the range of factors that marks exactly 80 cells (if the 80th and 81st values differ)
+    rng = f"({srt[80] / mx:.4f}, {srt[79] / mx:.4f}]" if len(srt) > 80 and srt[79] > srt[80] else "none (tie at the 80th cell)"
+    print(f"{name:70s} " + " ".join(f"{c:6d}" for c in counts) + "   " + rng)

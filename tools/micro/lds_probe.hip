@@ -79,6 +79,42 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, const u32x
       }
       t1 = __builtin_amdgcn_s_memtime();
       sink = acc;
+    } else if constexpr (TEST >= 5) {
+      // emulation of one SSOR sub-step of G = TEST - 4 groups: 8 G random y gathers + own y, 4 G + 1 sixteen-byte value reads,
+      // 10 sixteen-byte reads of the next sub-step's columns, the chain of 8 G multiply-adds, one y write
+      constexpr int G = TEST - 4;
+      uint32_t a[8 * G];
+#pragma unroll
+      for (int u = 0; u < 8 * G; ++u) a[u] = ((lane * 37 + u * 101) * 8) & 0x7ff8;
+      const uint32_t rec = 40000 + lane * (96 * G + 48), mine = lane * 8;
+      double carry = 0.0;
+      t0 = __builtin_amdgcn_s_memtime();
+      for (int i = 0; i < iters; ++i) {
+        double yv[8 * G], av[8 * G];
+#pragma unroll
+        for (int u = 0; u < 8 * G; ++u) yv[u] = lds_ld<double>(a[u]);
+        const double yold = lds_ld<double>(mine);
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+          typedef double f64x2 __attribute__((ext_vector_type(2)));
+          const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
+          av[2 * j] = a2.x; av[2 * j + 1] = a2.y;
+        }
+        u32x4 nx[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) nx[j] = lds_ld<u32x4>(rec + 16 * j + (i & 1) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        double acc = carry;
+#pragma unroll
+        for (int u = 0; u < 8 * G; ++u) acc += av[u] * yv[u];
+        carry = acc * 1e-30;
+        lds_st<double>(mine, yold + acc * 1e-30);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (a[u] + (nx[u].x & 8)) & 0x7ff8;  // the prefetched columns feed the next gathers
+        sink += (double)(nx[8].x + nx[9].y);
+      }
+      t1 = __builtin_amdgcn_s_memtime();
+      sink += carry;
     } else if constexpr (TEST == 4) {  // write then dependent read of the same address (y hand-over between steps)
       t0 = __builtin_amdgcn_s_memtime();
       double v = lane;
@@ -96,7 +132,7 @@ __global__ __launch_bounds__(256) void probe(unsigned long long *out, const u32x
 
 template <int TEST>
 void run(const char *name, double ops_per_iter, const u32x4 *src, unsigned long long *out) {
-  for (int active : {64, 13})
+  for (int active : {64, 21})
     for (int others = 0; others < 3; ++others) {
       const int iters = 2000;
       hipFuncSetAttribute((const void *)probe<TEST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -118,5 +154,8 @@ int main() {
   run<2>("8 independent ds_read_b128 + use", 8, src, out);
   run<3>("dependent DP mul+add pair", 16, src, out);
   run<4>("ds_write_b64 -> ds_read_b64 same address", 16, src, out);
+  run<6>("sub-step emulation, 2 groups (16 entries)", 1, src, out);
+  run<7>("sub-step emulation, 3 groups (24 entries)", 1, src, out);
+  run<8>("sub-step emulation, 4 groups (32 entries)", 1, src, out);
   return 0;
 }

@@ -15,7 +15,8 @@ for key in ("cluster/SSOR_run", "cluster/SSOR_64k_atoms"):
         if run.get("n_atoms") == 8 * nacl ** 3:
             gold = run["cycles"]
 p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
-                         cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother=smoother, ssor_blocks=blocks))
+                         cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother=smoother, ssor_blocks=blocks,
+                         refinement_estimator=os.environ.get("STEP50_ESTIMATOR", "Kelly")))
 p.set_nacl_atoms(nacl)
 for c in range(cycles):
     t = time.time()

@@ -11,7 +11,8 @@ nacl = int(sys.argv[1]); cycles = int(sys.argv[2]); blocks = int(sys.argv[3]) if
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 opts = os.environ.pop("GMG_OPTIONS", "")
 p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
-                         cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi"))
+                         cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi",
+                         refinement_estimator=os.environ.get("STEP50_ESTIMATOR", "Kelly")))
 p.set_nacl_atoms(nacl)
 for c in range(cycles):
     r = p.run_cycle(c)
