@@ -116,6 +116,7 @@ struct gmg_context {
   double *part_a = nullptr, *part_b = nullptr;  // reduction partials (4 * kMaxPartials each)
   double *scal_dev = nullptr;                   // 8 doubles
   double *scal_host = nullptr;                  // pinned, 8 doubles
+  int *sgs_abort = nullptr;                     // pinned, device-visible: set by the SSOR sweep if its wave protocol broke
   // tuning / measurement
   int coarse_chunk = 0;
   // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
@@ -659,6 +660,7 @@ int spmv(gmg_context *ctx, const DevCSR &m, int mode, const double *x, double *y
 int fetch_scalars(gmg_context *ctx, int n) {
   HIPC(hipMemcpyAsync(ctx->scal_host, ctx->scal_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIPC(stream_wait(ctx->stream));
+  if (*ctx->sgs_abort) return fail(ctx, GMG_ERR_HIP, "SSOR sweep: a wave gave up waiting for its partner (internal protocol error)");
   if (ctx->comm.n_ranks > 1) {
     // sums: slots flagged by the caller; handled in the callers below
   }
@@ -721,7 +723,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
     p.ranges = L.sgs.w_ranges; p.block_rng = L.sgs.w_block_rng; p.stream = L.sgs.w_stream; p.ws_ci = L.sgs.w_ws_ci;
     p.ci_row = L.sgs.w_ci_row; p.ycur = L.sgs.w_ycur; p.y = y; p.omega = ctx->omega; p.y_slots = L.sgs.w_y_slots;
     p.row_ci = L.sgs.w_row_ci; p.rpos_f = L.sgs.w_rpos_f; p.rpos_b = L.sgs.w_rpos_b; p.iso_diag = L.sgs.w_iso_diag;
-    p.iso_invd = L.sgs.w_iso_invd; p.r = r; p.n_rows = L.n;
+    p.iso_invd = L.sgs.w_iso_invd; p.r = r; p.n_rows = L.n; p.abort_flag = ctx->sgs_abort;
     hipLaunchKernelGGL(sgs_wave_prepass_kernel, dim3(grid_for(L.n)), dim3(256), 0, ctx->stream, p);
     if (L.sgs.w_n_coupled > 0) {
       if (ctx->sgs_profile) return sgs_profile_launch(ctx, L, p);
@@ -1346,7 +1348,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   HIPC(hipMalloc(&G.w_ycur, sizeof(double) * std::max<size_t>(ci_row.size(), 1)));
   HIPC(hipStreamSynchronize(ctx->stream));
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = y_slots * 8 + kSwRing + 16 + kSwSlack;
+  G.w_lds_bytes = y_slots * 8 + kSwRing + 32;
   G.w_n_ranges = (int)ranges.size();
   G.w_n_coupled = (int64_t)ci_row.size();
   G.w_stream_bytes = (int64_t)stream.size();
@@ -1474,6 +1476,8 @@ int gmg_create(gmg_context **out, int device_id, int n_levels) {
   if (hipMalloc(&ctx->part_b, sizeof(double) * 4 * kMaxPartials) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipMalloc(&ctx->scal_dev, sizeof(double) * 8) != hipSuccess) return bail(GMG_ERR_HIP);
   if (hipHostMalloc((void **)&ctx->scal_host, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess) return bail(GMG_ERR_HIP);
+  if (hipHostMalloc((void **)&ctx->sgs_abort, sizeof(int), hipHostMallocDefault) != hipSuccess) return bail(GMG_ERR_HIP);
+  *ctx->sgs_abort = 0;
   (void)hipMemsetAsync(ctx->st, 0, sizeof(CGState), ctx->stream);
   // measurement scripts reach the diagnostic options of a context they do not create themselves through
   // GMG_OPTIONS="key=value,key=value" (same keys as gmg_set_option); unknown keys fail the creation
@@ -1509,6 +1513,7 @@ int gmg_destroy(gmg_context *ctx) {
   for (auto &e : ctx->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (ctx->scal_host) (void)hipHostFree(ctx->scal_host);
+  if (ctx->sgs_abort) (void)hipHostFree(ctx->sgs_abort);
   for (auto *v : {&ctx->ev_a, &ctx->ev_b, &ctx->ev_c, &ctx->ev_d, &ctx->ev_e, &ctx->ev_f})
     for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

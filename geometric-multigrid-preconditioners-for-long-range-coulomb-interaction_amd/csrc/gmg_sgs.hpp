@@ -37,8 +37,9 @@ constexpr int kSwRing = 32768;     // bytes of the record ring in LDS
 constexpr int kSwChunk = 4096;     // unit the helper waves copy
 constexpr int kSwW = 32;           // most entries per sub-step: a row's sum is formed in groups of 8 products, 1..4 groups per sub-step
 constexpr int kSwMaxBlock = 8192;  // bytes of one step's records: 3 blocks + 1 chunk fit the ring (no deadlock)
-constexpr int kSwSlack = 0;
+
 constexpr int kSwYSlots = 15744;   // doubles of y in LDS (123 KB) by default
+constexpr uint32_t kSwSpinLimit = 1u << 22;  // polls (> 0.1 s) after which a waiting wave declares the sweep broken
 constexpr int kSwThreads = 256;    // wave 0 computes, waves 1..3 stream
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.
@@ -95,6 +96,7 @@ struct SgsWaveArgs {
   const double *iso_invd;    // level row -> 1 / a_ii
   const double *r;
   int64_t n_rows;
+  int *abort_flag;           // host-visible: set when a wave of the sweep gave up waiting for its partner (results invalid)
   int prof_mode;             // PROFILE variant, timing experiments (wrong results): 1 no chain, 2 no y gathers, 3 no a reads, 4 no next-column prefetch, 5 empty sub-step
   unsigned long long *prof;  // PROFILE variant: per range {cycles of the sweep, of them waiting for the ring, working-set load, write-back}
 };
@@ -183,15 +185,19 @@ template <int G, bool FWD, bool PROFILE>
 __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, uint32_t ctr0, int lane, double omega, double *stream_d,
                                             unsigned long long &t_wait, int mode) {
   uint32_t pos = 0, avail = 0;
+  bool ok = true;  // false once a wave of the workgroup gave up waiting (ctr[4]): everybody leaves for the barrier
   auto wait_for = [&](uint32_t end) {
-    if (avail >= end) return;
+    if (__builtin_expect(avail >= end, 1)) return;  // the helpers run ahead: keep the hot path free of taken branches
     unsigned long long w0 = 0;
     if constexpr (PROFILE) w0 = __builtin_amdgcn_s_memtime();
-    while (avail < end) {
+    for (uint32_t spins = 0; avail < end; ++spins) {
       const uint32_t d0 = ld_acq(ctr0), d1 = ld_acq(ctr0 + 4), d2 = ld_acq(ctr0 + 8);
       const uint32_t q = min(min(d0 * 3u, d1 * 3u + 1u), d2 * 3u + 2u);  // chunks [0, q) are in the ring
       avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(q * (uint32_t)kSwChunk));
-      if (avail < end) __builtin_amdgcn_s_sleep(1);
+      if (avail >= end) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (spins > kSwSpinLimit) st_rlx(ctr0 + 16, 1u);
+      if ((spins & 63u) == 63u && __builtin_amdgcn_readfirstlane((int)ld_acq(ctr0 + 16))) { ok = false; break; }
     }
     if constexpr (PROFILE) t_wait += __builtin_amdgcn_s_memtime() - w0;
   };
@@ -223,9 +229,9 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
       // everything in front of this sub-step's records may be overwritten (relaxed: the LDS queue of this wave is in
       // order, the store cannot overtake the reads issued before it)
       st_rlx(ctr0 + 12, pos);
-      if (next_raw) {
+      if (__builtin_expect(next_raw != 0, 1)) {
         wait_for(pos + advance + next_raw);
-        nxt = load_next<G>(ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane);
+        nxt = load_next<G>(ring0 + ((pos + advance) & (uint32_t)(kSwRing - 1)), n_nrows, lane);  // (after a failed wait: stale bytes, LDS only)
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- the dependent chain, in CSR order
@@ -235,7 +241,7 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
         for (int k = 0; k < 8 * G; ++k) acc += av[k] * yv[k];
       }
       carry = acc;
-      if ((flags & 2u) && lane < nrows) {
+      if ((flags & 2u) && lane < nrows && ok) {  // (ok: no global store from stale records)
         if constexpr (FWD) stream_d[cur.aux] = acc;
         lds_st<double>(cur.my, yold + (omega * (ri.x - acc)) * ri.y);
       }
@@ -247,8 +253,9 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
     nrows = n_nrows;
   };
   wait_for((uint32_t)R.first_raw);
+  if (!ok) return;
   NextCols<G> C0 = load_next<G>(ring0, nrows, lane), C1 = C0;
-  for (int s = 0; s < R.n_steps; s += 2) {
+  for (int s = 0; s < R.n_steps && ok; s += 2) {
     one_step(C0, C1);
     if (s + 1 < R.n_steps) one_step(C1, C0);
   }
@@ -269,7 +276,7 @@ __device__ __forceinline__ void sweep_dispatch(const SwRange &R, uint32_t ring0,
 
 template <bool PROFILE>
 __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // at LDS address 0: [y slots][record ring][4 counters]
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // at LDS address 0: [y slots][record ring][5 counters]
   double *ylds = reinterpret_cast<double *>(lds);
   const uint32_t ring0 = (uint32_t)a.y_slots * 8u, ctr0 = ring0 + (uint32_t)kSwRing;
   char *ring = lds + ring0;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
       for (int j = 0; j < 8; ++j)
         if (ci[j] >= 0) ylds[k0 + j * kSwThreads] = v[j];
     }
-    if (tid < 4) sw::st_rlx(ctr0 + 4 * tid, 0u);
+    if (tid < 5) sw::st_rlx(ctr0 + 4 * tid, 0u);
     __syncthreads();
     if constexpr (PROFILE) t1 = __builtin_amdgcn_s_memtime();
     if (wid == 0) {
@@ -310,7 +317,13 @@ __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
         const uint4 *sq = src + (size_t)q * (kSwChunk / 16) + lane;
         const uint4 b0 = sq[0], b1 = sq[64], b2 = sq[128], b3 = sq[192];
         const uint32_t need = (uint32_t)(q + 1) * (uint32_t)kSwChunk;
-        while (need > (uint32_t)__builtin_amdgcn_readfirstlane((int)sw::ld_acq(ctr0 + 12)) + (uint32_t)kSwRing) __builtin_amdgcn_s_sleep(2);
+        bool h_ok = true;
+        for (uint32_t spins = 0; need > (uint32_t)__builtin_amdgcn_readfirstlane((int)sw::ld_acq(ctr0 + 12)) + (uint32_t)kSwRing; ++spins) {
+          __builtin_amdgcn_s_sleep(2);
+          if (spins > kSwSpinLimit) sw::st_rlx(ctr0 + 16, 1u);
+          if ((spins & 63u) == 63u && __builtin_amdgcn_readfirstlane((int)sw::ld_acq(ctr0 + 16))) { h_ok = false; break; }
+        }
+        if (!h_ok) break;
         uint4 *dst = reinterpret_cast<uint4 *>(ring + (((uint32_t)q * (uint32_t)kSwChunk) & (uint32_t)(kSwRing - 1))) + lane;
         dst[0] = b0; dst[64] = b1; dst[128] = b2; dst[192] = b3;
         ++done;
@@ -318,6 +331,10 @@ __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
       }
     }
     __syncthreads();
+    if (sw::ld_acq(ctr0 + 16)) {  // a wave gave up waiting: the sweep is broken (never seen; guards the GPU against a hang)
+      if (tid == 0) *a.abort_flag = 1;
+      return;
+    }
     if constexpr (PROFILE) t2 = __builtin_amdgcn_s_memtime();
     for (int k0 = tid; k0 < R.n_own; k0 += 8 * kSwThreads) {
       int ci[8], row[8];
