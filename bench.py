@@ -82,8 +82,9 @@ def main():
     ap.add_argument("--workload", default="atoms64000", choices=sorted(WORKLOADS))
     ap.add_argument("--smoother", default="SSOR", choices=["Jacobi", "SSOR", "Chebyshev"],
                     help="smoother of the headline solve (default: the reference's, src/step-50.cc:970)")
-    ap.add_argument("--ssor-blocks", type=int, default=1,
-                    help="SSOR as the reference applies it on this many MPI ranks (1 = exact sequential sweep)")
+    ap.add_argument("--ssor-blocks", type=int, default=None,
+                    help="SSOR as the reference applies it on this many MPI ranks (1 = exact sequential sweep); default: one block "
+                         "per rank, i.e. 1 on one GPU and N on N GPUs (each rank sweeps its block, as the reference's ranks do)")
     ap.add_argument("--no-smoother-table", action="store_true", help="skip the solves with the other smoothers (config.smoothers)")
     ap.add_argument("--cycles", type=int, default=5, help="adaptive cycles to run (the reference runs 5); the last one is timed")
     ap.add_argument("--partition-level0", default="auto", choices=["auto", "always", "never"],
@@ -114,6 +115,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.ssor_blocks is None:
+        args.ssor_blocks = world
 
     pkg = importlib.import_module(PKG)
     S = pkg.step50

@@ -68,6 +68,9 @@ struct SgsPlan {
   double *w_ycur = nullptr, *w_iso_diag = nullptr, *w_iso_invd = nullptr;
   int w_y_slots = 0, w_lds_bytes = 0, w_n_ranges = 0;
   int64_t w_n_coupled = 0, w_stream_bytes = 0, w_steps = 0, w_stages = 0;
+  std::vector<int32_t> host_block_row;  // n_blocks + 1 (several ranks: who sweeps which rows)
+  double *w_stage = nullptr;            // staging of the all-gather of the swept pieces
+  int64_t w_stage_len = 0;
 };
 
 struct Level {
@@ -725,6 +728,12 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
     p.row_ci = L.sgs.w_row_ci; p.rpos_f = L.sgs.w_rpos_f; p.rpos_b = L.sgs.w_rpos_b; p.iso_diag = L.sgs.w_iso_diag;
     p.iso_invd = L.sgs.w_iso_invd; p.r = r; p.n_rows = L.n; p.abort_flag = ctx->sgs_abort;
     hipLaunchKernelGGL(sgs_wave_prepass_kernel, dim3(grid_for(L.n)), dim3(256), 0, ctx->stream, p);
+    // one process per GPU: the blocks are what the reference's ranks sweep -- each rank sweeps its share of them and
+    // the pieces of y are all-gathered (levels >= 1 are replicated: every rank needs the whole vector)
+    const int n_ranks = ctx->dist ? ctx->comm.n_ranks : 1;
+    const bool split = n_ranks > 1 && L.sgs.n_blocks % n_ranks == 0 && !ctx->sgs_profile;
+    const int nbl = split ? L.sgs.n_blocks / n_ranks : L.sgs.n_blocks;
+    p.block0 = split ? ctx->comm.rank * nbl : 0;
     if (L.sgs.w_n_coupled > 0) {
       if (ctx->sgs_profile) return sgs_profile_launch(ctx, L, p);
       if (ctx->prof_every > 0 && !ctx->ev_e.empty()) {
@@ -734,7 +743,26 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
         ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
       }
       const size_t lds = ctx->sgs_lds_bytes_override > 0 ? (size_t)ctx->sgs_lds_bytes_override : (size_t)L.sgs.w_lds_bytes;
-      launch_timed(ctx, sgs_wave_kernel<false>, dim3(L.sgs.n_blocks), dim3(kSwThreads), lds, p);
+      launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
+    }
+    if (split) {
+      const std::vector<int32_t> &br = L.sgs.host_block_row;
+      const int64_t len = L.sgs.w_stage_len;
+      auto piece = [&](int r, int64_t *b, int64_t *e) { *b = br[(size_t)(r * nbl)]; *e = br[(size_t)((r + 1) * nbl)]; };
+      int64_t b, e;
+      piece(ctx->comm.rank, &b, &e);
+      double *mine = L.sgs.w_stage + (int64_t)ctx->comm.rank * len;
+      if (e > b) HIPC(hipMemcpyAsync(mine, y + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
+      if (ctx->comm.shm) {
+        if (shm_allgather(ctx->comm, L.sgs.w_stage, len, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "SSOR: all-gather (shared memory) failed");
+      } else if (ncclAllGather(mine, L.sgs.w_stage, (size_t)len, ncclDouble, ctx->comm.comm, ctx->stream) != ncclSuccess) {
+        return fail(ctx, GMG_ERR_COMM, "SSOR: all-gather failed");
+      }
+      for (int r = 0; r < n_ranks; ++r) {
+        if (r == ctx->comm.rank) continue;
+        piece(r, &b, &e);
+        if (e > b) HIPC(hipMemcpyAsync(y + b, L.sgs.w_stage + (int64_t)r * len, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
+      }
     }
     HIPC(hipGetLastError());
     return GMG_OK;
@@ -1069,7 +1097,7 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
 void free_sgs(SgsPlan &g) {
   for (void *p : {(void *)g.stage_ptr, (void *)g.stage_rows, (void *)g.block_row, (void *)g.block_stage, (void *)g.w_ranges,
                   (void *)g.w_block_rng, (void *)g.w_ws_ci, (void *)g.w_ci_row, (void *)g.w_row_ci, (void *)g.w_rpos_f, (void *)g.w_rpos_b,
-                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd})
+                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd, (void *)g.w_stage})
     if (p) (void)hipFree(p);
   g = SgsPlan();
 }
@@ -1347,6 +1375,17 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
 #undef SW_UP
   HIPC(hipMalloc(&G.w_ycur, sizeof(double) * std::max<size_t>(ci_row.size(), 1)));
   HIPC(hipStreamSynchronize(ctx->stream));
+  G.host_block_row = block_row;
+  {
+    const int n_ranks = ctx->dist ? ctx->comm.n_ranks : 1;
+    if (n_ranks > 1 && n_blocks % n_ranks == 0) {
+      const int nbl = n_blocks / n_ranks;
+      int64_t len = 1;
+      for (int r = 0; r < n_ranks; ++r) len = std::max<int64_t>(len, block_row[(size_t)((r + 1) * nbl)] - block_row[(size_t)(r * nbl)]);
+      G.w_stage_len = len;
+      HIPC(hipMalloc(&G.w_stage, sizeof(double) * (size_t)(len * n_ranks)));
+    }
+  }
   G.w_y_slots = y_slots;
   G.w_lds_bytes = y_slots * 8 + kSwRing + 32;
   G.w_n_ranges = (int)ranges.size();

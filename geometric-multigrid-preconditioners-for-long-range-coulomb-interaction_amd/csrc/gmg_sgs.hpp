@@ -82,6 +82,7 @@ __host__ __device__ constexpr int sw_stride(int g) { return 96 * g + 48; }
 struct SgsWaveArgs {
   const SwRange *ranges;
   const int32_t *block_rng;  // n_blocks + 1: ranges of each block (forward ones first)
+  int block0;                // first block of this launch (several ranks: each sweeps its share of the blocks)
   char *stream;
   const int32_t *ws_ci;      // working-set lists (compact row ids), own rows first
   const int32_t *ci_row;     // compact id -> level row
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(kSwThreads) void sgs_wave_kernel(SgsWaveArgs a) {
   const uint32_t ring0 = (uint32_t)a.y_slots * 8u, ctr0 = ring0 + (uint32_t)kSwRing;
   char *ring = lds + ring0;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r_begin = a.block_rng[blockIdx.x], r_end = a.block_rng[blockIdx.x + 1];
+  const int r_begin = a.block_rng[a.block0 + blockIdx.x], r_end = a.block_rng[a.block0 + blockIdx.x + 1];
   for (int rg = r_begin; rg < r_end; ++rg) {
     const SwRange R = a.ranges[rg];
     const int32_t *ws = a.ws_ci + R.ws_off;

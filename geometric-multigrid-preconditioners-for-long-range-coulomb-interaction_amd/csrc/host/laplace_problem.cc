@@ -1014,7 +1014,8 @@ int LaplaceProblem<dim>::upload() {
     GMGC(gmg_reset(gmg, L));  // the context may have been created early (charge densities) with 1 level
   }
   operators_uploaded = true;
-  GMGC(gmg_set_ssor_blocks(gmg, par.ssor_blocks));  // before the level matrices: sizes the SGS schedule
+  // before the level matrices: sizes the SGS schedule.  0 = one block per rank: the reference's smoother on that many ranks
+  GMGC(gmg_set_ssor_blocks(gmg, par.ssor_blocks > 0 ? par.ssor_blocks : std::max(1, distributed ? n_ranks : 1)));
   const CSRMatrix &S = system_matrix;
   if (distributed) {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),
@@ -1192,7 +1193,7 @@ int LaplaceProblem<dim>::set_smoother(const std::string &smoother, int ssor_bloc
   if (smoother != "Jacobi" && smoother != "SSOR" && smoother != "Chebyshev") { last_error = "unknown smoother " + smoother; return GMG_ERR_INVALID; }
   if (!operators_uploaded) { last_error = "set_smoother: no cycle has been run"; return GMG_ERR_INVALID; }
   par.smoother = smoother;
-  par.ssor_blocks = std::max(1, ssor_blocks);
+  par.ssor_blocks = std::max(0, ssor_blocks);
   return upload();
 }
 

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None, part="always"):
+def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None, part="always", blocks=1):
     """n_ranks = 0: one plain process without a communicator (the single-GPU layout)"""
     monkeypatch.setenv("GMG_COMM_TRANSPORT", "shm")
     monkeypatch.setenv("GMG_SHM_SLOT_MB", "8")
@@ -31,9 +31,9 @@ def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None
     name = uid[len(b"GMGSHM:"):].split(b"\0")[0].decode()
     env = dict(os.environ)
     env.update(env_extra or {})
-    outs = [str(tmp_path / f"n{n_ranks}_{part}_rank{r}.json") for r in range(max(1, n_ranks))]
+    outs = [str(tmp_path / f"n{n_ranks}_{part}_b{blocks}_rank{r}.json") for r in range(max(1, n_ranks))]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(n_ranks), uid.hex(), golden_dir,
-                               outs[r]] + ([str(nacl), part] if nacl else []), env=env) for r in range(max(1, n_ranks))]
+                               outs[r]] + ([str(nacl), part, str(blocks)] if (nacl or blocks != 1) else []), env=env) for r in range(max(1, n_ranks))]
     try:
         for p in procs:
             assert p.wait(timeout=280) == 0
@@ -78,4 +78,18 @@ def test_three_kernel_coarse_cg_on_two_and_three_ranks(golden_dir, tmp_path, mon
         for r, g in zip(reps, one):
             assert r["dofs_by_level"] == g["dofs_by_level"] and r["cg_iterations"] == g["cg_iterations"]
             for k in ("sol_l1", "sol_l2", "sol_linf", "rhs_l2", "starting_value"):
+                assert rel_close(r[k], g[k], 9), (k, r[k], g[k])
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_block_ssor_swept_by_the_ranks(golden_dir, tmp_path, monkeypatch, n_ranks):
+    """SSOR on N ranks as the reference applies it: N blocks, one per rank.  Every rank sweeps only its block and the
+    pieces are all-gathered; the result must be what ONE process computes with the same N blocks (six adaptive cycles
+    of the 2-atom problem: multi-level V-cycles with edge matrices)."""
+    ranks = run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, blocks=n_ranks)
+    one = run_ranks(0, golden_dir, tmp_path, monkeypatch, blocks=n_ranks)[0]
+    for reps in ranks:
+        for r, g in zip(reps, one):
+            assert r["dofs_by_level"] == g["dofs_by_level"] and r["cg_iterations"] == g["cg_iterations"]
+            for k in ("sol_l1", "sol_l2", "sol_linf", "starting_value", "refine_threshold", "energy_total"):
                 assert rel_close(r[k], g[k], 9), (k, r[k], g[k])

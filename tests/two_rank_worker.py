@@ -3,7 +3,7 @@
 test with the solve on the GPU in the one-process-per-GPU layout (partitioned system matrix and
 level 0, halo exchange, all-reduces, all-gathers), on the communicator named by the id.
 
-usage: two_rank_worker.py RANK N_RANKS ID_HEX GOLDEN_DIR OUT_JSON [nacl [auto|always|never]]"""
+usage: two_rank_worker.py RANK N_RANKS ID_HEX GOLDEN_DIR OUT_JSON [nacl [auto|always|never [ssor_blocks]]]"""
 import json
 import os
 import sys
@@ -18,6 +18,7 @@ def main():
     golden_dir, out = sys.argv[4], sys.argv[5]
     nacl = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     part = sys.argv[7] if len(sys.argv) > 7 else "always"  # small problems: "auto" would keep level 0 replicated
+    blocks = int(sys.argv[8]) if len(sys.argv) > 8 else 1   # SSOR blocks (0: one per rank, the reference on that many ranks)
     S = pkg().step50
     if nacl:  # lattice of nacl^3 atoms, Jacobi smoother: the bench's kind of problem, three-kernel coarse CG on request
         cycles = 2
@@ -29,7 +30,7 @@ def main():
         cycles = 6
         p = S.Problem(S.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Exact",
                                  cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=4, global_refinement=0,
-                                 smoother="SSOR", partition_level0=part))
+                                 smoother="SSOR", partition_level0=part, ssor_blocks=blocks))
         p.read_lammps(os.path.join(golden_dir, "atom_n1_2.data"))
     if n_ranks > 0:
         p.set_communicator(rank, n_ranks, uid)
