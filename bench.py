@@ -222,8 +222,8 @@ def main():
         val8, col16 = bool(lay >= 1 and (lay - 1) & 2), bool(lay >= 1 and (lay - 1) & 4)
         tmpl = f"0, {1 if fused else 2}" + (f", {'true' if val8 else 'false'}, {'true' if col16 else 'false'}" if lay >= 1 else "")
         kname = ("spmv_sell_kernel" if lay >= 1 else "spmv_tile_kernel") + f"<{tmpl}>"
-        if lay >= 1 and (lay - 1) & 8:  # lattice operator: pattern-run kernel (pair loads + lane shift)
-            kname = f"spmv_sellp_kernel<0, {1 if fused else 2}>"
+        if lay >= 1 and (lay - 1) & 8:  # lattice operator: pattern-run kernel (pair loads + lane shift), with row classes or value codes
+            kname = f"spmv_sellp_kernel<0, {1 if fused else 2}, {'true' if (lay - 1) & 16 else 'false'}>"
         # bytes the kernel actually moves: the operator in its device layout (SELL-64, 1-byte value codes, column
         # patterns: the library reports the exact size of the streams) + x read + y written (+ g, d when fused)
         moved = int(st.spmv0_matrix_bytes) + 16 * n0 + (16 * n0 if fused else 8 * n0)

@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -49,6 +50,10 @@ struct DevCSR {
   int sellp_pid = -1, sellp_centre[9] = {};  // the nine-runs-of-three pattern served by spmv_sellp_kernel
   int32_t *sellp_wave_ptr = nullptr;          // slice range of every wave of spmv_sellp_kernel
   bool use_sellp = false;
+  bool rowclass = false;  // run-pattern slices take their coefficients from a per-row class table (N4)
+  uint8_t *sellp_rowcls = nullptr;
+  double *sellp_ctab = nullptr;
+  int n_classes = 0;
   int n_patterns = 0, n_pattern_slices = 0;
   bool val8 = false, col16 = false;
   int n_slices = 0, sell_grid = 0;
@@ -128,7 +133,7 @@ struct gmg_context {
   int sgs_profile_mode = 0;
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
-  bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false;
+  bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false;
   int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
   double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
   int ssor_blocks = 1;  // 1 = exact sequential SGS; B > 1 = block Jacobi of SGS (the reference on B ranks)
@@ -213,6 +218,8 @@ void free_csr(DevCSR &m) {
   if (m.tile_row) (void)hipFree(m.tile_row);
   if (m.slice_ptr) (void)hipFree(m.slice_ptr);
   if (m.sellp_wave_ptr) (void)hipFree(m.sellp_wave_ptr);
+  if (m.sellp_rowcls) (void)hipFree(m.sellp_rowcls);
+  if (m.sellp_ctab) (void)hipFree(m.sellp_ctab);
   if (m.slice_base) (void)hipFree(m.slice_base);
   if (m.sell_vals) (void)hipFree(m.sell_vals);
   if (m.sell_cols) (void)hipFree(m.sell_cols);
@@ -544,6 +551,36 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
           HIPC(hipMalloc(&m.sellp_wave_ptr, sizeof(int32_t) * wp.size()));
           HIPC(hipMemcpyAsync(m.sellp_wave_ptr, wp.data(), sizeof(int32_t) * wp.size(), hipMemcpyHostToDevice, ctx->stream));
           HIPC(hipStreamSynchronize(ctx->stream));
+          // ---- row classes of the run-pattern slices (N4): the 27-tuple of value codes of a row; a lattice operator
+          // has a few dozen of them.  Too many classes (> kSellpMaxClasses): the per-entry codes stay in use.
+          if (!ctx->disable_rowclass) {
+            std::vector<uint8_t> rowcls((size_t)n_rows, 0);
+            std::map<std::array<uint8_t, 27>, int> cls_of;
+            std::vector<double> ctab;
+            bool ok = true;
+            for (size_t s2 = 0; s2 < (size_t)n_slices && ok; ++s2) {
+              if (spat[s2] != m.sellp_pid) continue;
+              for (int lane = 0; lane < 64 && ok; ++lane) {
+                std::array<uint8_t, 27> key;
+                for (int j = 0; j < 27; ++j) key[(size_t)j] = v1[(size_t)((((int64_t)sp[s2] + j / 4) * 64 + lane) * 4 + (j & 3))];
+                auto ins = cls_of.emplace(key, (int)cls_of.size());
+                if (ins.second) {
+                  if ((int)cls_of.size() > kSellpMaxClasses) { ok = false; break; }
+                  for (int j = 0; j < 27; ++j) ctab.push_back(dict[key[(size_t)j]]);
+                }
+                rowcls[s2 * 64 + (size_t)lane] = (uint8_t)ins.first->second;
+              }
+            }
+            if (ok && !cls_of.empty()) {
+              HIPC(hipMalloc(&m.sellp_rowcls, rowcls.size()));
+              HIPC(hipMalloc(&m.sellp_ctab, sizeof(double) * ctab.size()));
+              HIPC(hipMemcpyAsync(m.sellp_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice, ctx->stream));
+              HIPC(hipMemcpyAsync(m.sellp_ctab, ctab.data(), sizeof(double) * ctab.size(), hipMemcpyHostToDevice, ctx->stream));
+              HIPC(hipStreamSynchronize(ctx->stream));
+              m.rowclass = true;
+              m.n_classes = (int)cls_of.size();
+            }
+          }
         }
       }
       if (!keep_csr) {  // the CSR copy is only kept where the SGS sweeps need it (levels >= 1)
@@ -556,6 +593,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
   if (ctx->debug_upload)
     std::fprintf(stderr, "[gmg] operator %lld x %lld nnz %lld: tiles %d grid %d sell %d val8 %d col16 %d sell_grid %d patterns %d pattern_slices %d/%d\n", (long long)n_rows,
                  (long long)n_cols, (long long)nnz, m.n_tiles, m.grid, (int)m.sell, (int)m.val8, (int)m.col16, m.sell_grid, m.n_patterns, m.n_pattern_slices, m.n_slices);
+  if (ctx->debug_upload && m.rowclass) std::fprintf(stderr, "[gmg]   row classes of the run-pattern slices: %d\n", m.n_classes);
   return GMG_OK;
 }
 
@@ -610,7 +648,9 @@ int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
       SellPatArgs pa{};
       pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
       for (int u = 0; u < 9; ++u) pa.centre[u] = m.sellp_centre[u];
-      launch_timed(ctx, spmv_sellp_kernel<MODE, CG>, dim3(m.sell_grid), dim3(kThreads), 0, pa);
+      pa.rowcls = m.sellp_rowcls; pa.ctab = m.sellp_ctab; pa.n_classes = m.n_classes;
+      if (m.rowclass) launch_timed(ctx, spmv_sellp_kernel<MODE, CG, true>, dim3(m.sell_grid), dim3(kThreads), 0, pa);
+      else launch_timed(ctx, spmv_sellp_kernel<MODE, CG, false>, dim3(m.sell_grid), dim3(kThreads), 0, pa);
       return m.sell_grid;
     }
     if (m.val8 && m.col16) launch_timed(ctx, spmv_sell_kernel<MODE, CG, true, true>, dim3(m.sell_grid), dim3(kThreads), 0, sa);
@@ -1631,7 +1671,10 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     if (L.A.sell) {
       const double frac_stream = L.A.n_slices ? 1.0 - (double)L.A.n_pattern_slices / L.A.n_slices : 1.0;
       const int64_t ent = L.A.sell_quads * 256;
-      ctx->stats.spmv0_matrix_bytes = ent * (L.A.val8 ? 1 : 8) + (int64_t)(frac_stream * (double)ent * (L.A.col16 ? 2 : 4)) + 8 * (int64_t)L.A.n_slices;
+      // row classes: the run-pattern slices stream one byte per row instead of one per entry
+      const int64_t val_bytes = L.A.rowclass ? (int64_t)(frac_stream * (double)ent) + (int64_t)L.A.n_pattern_slices * 64 : ent * (L.A.val8 ? 1 : 8);
+      ctx->stats.spmv0_matrix_bytes = val_bytes + (int64_t)(frac_stream * (double)ent * (L.A.col16 ? 2 : 4)) + 8 * (int64_t)L.A.n_slices;
+      if (L.A.rowclass) ctx->stats.spmv0_layout += 16;
     } else {
       ctx->stats.spmv0_matrix_bytes = 12 * rowptr[n_rows] + 4 * (n_rows + 1);
     }
@@ -2139,6 +2182,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "disable_patterns") ctx->disable_patterns = on;
   else if (k == "disable_compression") ctx->disable_compression = on;
   else if (k == "disable_sellp") ctx->disable_sellp = on;
+  else if (k == "disable_rowclass") ctx->disable_rowclass = on;
   else if (k == "sell_grid") ctx->sell_grid = (int)value;
   else if (k == "sellp_cost") ctx->sellp_cost = value;
   else if (k == "cg_variant") ctx->cg_variant = (int)value;

@@ -174,7 +174,7 @@ typedef struct gmg_stats {
   int64_t cgupd_samples;
   double cgupd_ms_total;
   int64_t coarse_variant;       /* 1 = fused (SpMV + direction update), 2 = unfused, of the last solve */
-  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) */
+  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) + 16 (row classes) */
   int64_t spmv0_matrix_bytes;   /* bytes of the level-0 operator one SpMV streams in its device layout */
   int64_t spmv0_pattern_slices, spmv0_slices; /* slices served by a column pattern / all slices */
   int64_t coarse_enqueued;      /* coarse iterations enqueued, incl. those that returned at once after convergence */
@@ -197,7 +197,7 @@ int gmg_calibrate_hbm(gmg_context *ctx, int64_t n_bytes, int reps, double *read_
  * forms d = beta d - g), 2 three-kernel iteration.                                          */
 int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant);
 /* Diagnostic / measurement options by name (defaults are the production paths).  Keys: host_threads,
- * debug_upload, disable_sell, disable_patterns, disable_compression, disable_sellp, sell_grid, sellp_cost,
+ * debug_upload, disable_sell, disable_patterns, disable_compression, disable_sellp, disable_rowclass, sell_grid, sellp_cost,
  * cg_variant, coarse_chunk, sgs_y_slots (doubles of LDS the SSOR sweep may use for y: small values force
  * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep), sgs_profile (instrumented sweep),
  * sgs_lds_bytes_override (tests: a value over the CU's 160 KB makes the sweep's launch fail -> GMG_ERR_HIP).  Options that shape a device
