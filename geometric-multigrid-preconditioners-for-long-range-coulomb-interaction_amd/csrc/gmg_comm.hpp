@@ -1,16 +1,21 @@
-// gmg_comm.hpp -- RCCL (xGMI) communicator, halo plans and scalar all-reduces.
+// gmg_comm.hpp -- one process per GPU: halo exchange, scalar all-reduces and all-gathers between the ranks.
 //
-// Two transports behind the same calls: RCCL (the product path: one process per GPU over xGMI)
-// and, selected by GMG_COMM_TRANSPORT=shm when the id is created, host-staged POSIX shared
-// memory for ranks of one node -- slow (every call synchronises the stream), but it lets two
-// processes share ONE GPU, which RCCL refuses, so the rank-parallel layout (halo pack/unpack,
-// partitioned level 0, all-gathers) is exercised end to end on a single-GPU box
-// (tests/test_gpu_two_ranks.py).
+// Stands in for what Epetra_MpiComm / Epetra_Import / MPI_Allreduce do underneath the reference's vmult and vector
+// reductions (collective table): the ghost values of an operator's column space are appended
+// behind the locally owned entries of the vector, in neighbour order.
 //
-// Stands in for what Epetra_MpiComm / Epetra_Import / MPI_Allreduce do underneath the
-// reference's vmult and vector reductions (collective table): one
-// process per GPU, the ghost values of an operator's column space are appended behind the
-// locally owned entries of the vector, in neighbour order.
+// Two transports behind the same four calls:
+//   * RCCL (ncclSend/Recv groups, ncclAllReduce, ncclAllGather over xGMI) -- selected by an id from ncclGetUniqueId.
+//   * PEER (GMG_COMM_TRANSPORT=peer when the id is created): every rank owns a "mailbox" in its HBM that its peers
+//     map with hipIpcOpenMemHandle (on one node: peer-to-peer stores over xGMI).  A message is written straight into
+//     the receiver's mailbox by a copy kernel of the sender, followed by a release store of a sequence number; the
+//     receiver's kernel polls that number (system-scope acquire), unpacks, and acknowledges.  No collective launch,
+//     no host synchronisation; the payload area is double-buffered by the sequence number's parity and a sender
+//     waits for the acknowledgement of the message two rounds back before it reuses a buffer.  Measured
+//     (tools/micro/ipc_probe.hip): 2.6 us one way between two processes.  Unlike RCCL this transport also works
+//     between processes that share ONE GPU, which is how the rank-parallel layout is tested on a single-GPU box
+//     (tests/test_gpu_two_ranks.py).  Every wait inside a kernel is bounded: a rank that waits > ~1 s raises an
+//     abort flag the host reports as GMG_ERR_COMM instead of hanging the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -30,51 +35,54 @@
 
 namespace gmg {
 
-constexpr int kShmMaxRanks = 8;
-constexpr char kShmTag[] = "GMGSHM:";
+constexpr int kPeerMaxRanks = 8;
+constexpr char kPeerTag[] = "GMGPEER:";
+constexpr int64_t kPeerFlagBytes = 4096;            // head of a mailbox: data_seq[src] at src * 128, ack_seq[dst] at 2048 + dst * 128
+constexpr long long kPeerSpinLimit = 400000000LL;   // polls (~1 s) after which a waiting kernel declares the exchange broken
 
-struct ShmHeader {  // zero-filled by ftruncate
+// start-up only: a POSIX shared-memory object carries the IPC handles and a host barrier
+struct PeerBoot {  // zero-filled by ftruncate
   std::atomic<int> arrived, generation;
-  int64_t slot_bytes;
-  int64_t seg_off[kShmMaxRanks][kShmMaxRanks];  // [sender][receiver]: offset (doubles) of the halo segment in the sender's slot
-  int64_t seg_cnt[kShmMaxRanks][kShmMaxRanks];
+  int64_t cap_bytes;  // payload capacity per (parity, source)
+  hipIpcMemHandle_t handle[kPeerMaxRanks];
 };
 
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
   bool ready = false;
-  // shared-memory transport
-  bool shm = false;
-  ShmHeader *hdr = nullptr;
-  char *slots = nullptr;
-  size_t map_bytes = 0;
-  char shm_name[96] = {};
-  double *slot(int r) const { return reinterpret_cast<double *>(slots + (size_t)r * (size_t)hdr->slot_bytes); }
+  // peer transport
+  bool peer = false;
+  PeerBoot *boot = nullptr;
+  char boot_name[96] = {};
+  char *box[kPeerMaxRanks] = {};  // device: my mailbox (box[rank]) and the peers' (IPC-mapped)
+  int64_t cap = 0;                // bytes per (parity, source)
+  unsigned long long seq = 0;     // collective rounds so far (the same on every rank: collectives are called in the same order)
+  unsigned long long last_sent[kPeerMaxRanks][2] = {};  // round of my last message to a peer, per parity
+  unsigned int *cnt = nullptr;    // device: workgroups done, per peer (last one publishes)
+  int *abort_host = nullptr;      // pinned: set by a kernel that gave up waiting
 };
 
-inline size_t shm_total_bytes(int64_t slot_bytes) { return 8192 + (size_t)kShmMaxRanks * (size_t)slot_bytes; }
-
-// every rank calls this the same number of times; gives up after 5 minutes (a peer died)
-inline int shm_barrier(Comm &c) {
-  const int gen = c.hdr->generation.load(std::memory_order_acquire);
-  if (c.hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c.n_ranks) {
-    c.hdr->arrived.store(0, std::memory_order_relaxed);
-    c.hdr->generation.fetch_add(1, std::memory_order_release);
+inline int boot_barrier(PeerBoot *b, int n_ranks) {
+  const int gen = b->generation.load(std::memory_order_acquire);
+  if (b->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n_ranks) {
+    b->arrived.store(0, std::memory_order_relaxed);
+    b->generation.fetch_add(1, std::memory_order_release);
     return 0;
   }
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;
-  while (c.hdr->generation.load(std::memory_order_acquire) == gen) {
+  while (b->generation.load(std::memory_order_acquire) == gen) {
     if ((++spins & 0xfff) == 0) {
       (void)sched_yield();
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) return 1;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return 1;
     }
   }
   return 0;
 }
 
 struct HaloPlan {
+  bool active = false;  // a plan was set for this operator (possibly with no neighbours: the rank still joins the round)
   int n_neighbors = 0;
   std::vector<int> rank, send_count, recv_count;
   int64_t total_send = 0, total_recv = 0;
@@ -90,6 +98,7 @@ inline void free_halo(HaloPlan &h) {
 
 inline int build_halo(HaloPlan &h, int n_neighbors, const int32_t *neighbor_rank, const int32_t *send_count,
                       const int32_t *send_idx, const int32_t *recv_count, hipStream_t stream) {
+  h.active = true;
   h.n_neighbors = n_neighbors;
   h.total_send = h.total_recv = 0;
   for (int i = 0; i < n_neighbors; ++i) {
@@ -112,23 +121,22 @@ inline int build_halo(HaloPlan &h, int n_neighbors, const int32_t *neighbor_rank
 inline int comm_unique_id(void *out) {
   static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId must fit GMG_UNIQUE_ID_BYTES");
   const char *tr = std::getenv("GMG_COMM_TRANSPORT");
-  if (tr && std::strcmp(tr, "shm") == 0) {
-    // the id names a fresh shared-memory object: header + one slot per rank
-    const char *mb = std::getenv("GMG_SHM_SLOT_MB");
-    const int64_t slot_bytes = (int64_t)(mb ? std::atoi(mb) : 16) << 20;
+  if (tr && std::strcmp(tr, "peer") == 0) {
+    // the id names a fresh shared-memory object used at start-up only (IPC handles + a host barrier)
+    const char *mb = std::getenv("GMG_PEER_SLOT_MB");
     char name[80];
-    std::snprintf(name, sizeof name, "/gmgshm_%d_%lld", (int)getpid(),
+    std::snprintf(name, sizeof name, "/gmgpeer_%d_%lld", (int)getpid(),
                   (long long)std::chrono::steady_clock::now().time_since_epoch().count());
     const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) return 1;
-    if (ftruncate(fd, (off_t)shm_total_bytes(slot_bytes)) != 0) { close(fd); shm_unlink(name); return 1; }
-    void *p = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (ftruncate(fd, (off_t)sizeof(PeerBoot)) != 0) { close(fd); shm_unlink(name); return 1; }
+    void *p = mmap(nullptr, sizeof(PeerBoot), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) { shm_unlink(name); return 1; }
-    static_cast<ShmHeader *>(p)->slot_bytes = slot_bytes;
-    munmap(p, sizeof(ShmHeader));
+    static_cast<PeerBoot *>(p)->cap_bytes = (int64_t)(mb ? std::atoi(mb) : 32) << 20;
+    munmap(p, sizeof(PeerBoot));
     memset(out, 0, 128);
-    std::snprintf(static_cast<char *>(out), 128, "%s%s", kShmTag, name);
+    std::snprintf(static_cast<char *>(out), 128, "%s%s", kPeerTag, name);
     return 0;
   }
   ncclUniqueId id;
@@ -139,24 +147,31 @@ inline int comm_unique_id(void *out) {
 }
 
 inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
-  if (std::memcmp(id_bytes, kShmTag, sizeof(kShmTag) - 1) == 0) {
-    static_assert(sizeof(ShmHeader) <= 8192, "header region");
-    if (n_ranks > kShmMaxRanks) return 1;
-    std::snprintf(c.shm_name, sizeof c.shm_name, "%s", static_cast<const char *>(id_bytes) + sizeof(kShmTag) - 1);
-    const int fd = shm_open(c.shm_name, O_RDWR, 0600);
+  if (std::memcmp(id_bytes, kPeerTag, sizeof(kPeerTag) - 1) == 0) {
+    if (n_ranks > kPeerMaxRanks) return 1;
+    std::snprintf(c.boot_name, sizeof c.boot_name, "%s", static_cast<const char *>(id_bytes) + sizeof(kPeerTag) - 1);
+    const int fd = shm_open(c.boot_name, O_RDWR, 0600);
     if (fd < 0) return 1;
-    void *h = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    if (h == MAP_FAILED) { close(fd); return 1; }
-    const int64_t slot_bytes = static_cast<ShmHeader *>(h)->slot_bytes;
-    munmap(h, sizeof(ShmHeader));
-    c.map_bytes = shm_total_bytes(slot_bytes);
-    void *p = mmap(nullptr, c.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    void *p = mmap(nullptr, sizeof(PeerBoot), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) return 1;
-    c.hdr = static_cast<ShmHeader *>(p);
-    c.slots = static_cast<char *>(p) + 8192;
-    c.rank = rank; c.n_ranks = n_ranks; c.shm = true; c.ready = true;
-    return shm_barrier(c);
+    c.boot = static_cast<PeerBoot *>(p);
+    c.cap = c.boot->cap_bytes;
+    c.rank = rank; c.n_ranks = n_ranks;
+    const size_t bytes = (size_t)kPeerFlagBytes + 2 * (size_t)n_ranks * (size_t)c.cap;
+    if (hipMalloc((void **)&c.box[rank], bytes) != hipSuccess) return 1;
+    if (hipMemset(c.box[rank], 0, (size_t)kPeerFlagBytes) != hipSuccess) return 1;
+    if (hipMalloc((void **)&c.cnt, sizeof(unsigned int) * 2 * kPeerMaxRanks) != hipSuccess) return 1;
+    if (hipMemset(c.cnt, 0, sizeof(unsigned int) * 2 * kPeerMaxRanks) != hipSuccess) return 1;
+    if (hipHostMalloc((void **)&c.abort_host, sizeof(int), hipHostMallocDefault) != hipSuccess) return 1;
+    *c.abort_host = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipIpcGetMemHandle(&c.boot->handle[rank], c.box[rank]) != hipSuccess) return 1;
+    if (boot_barrier(c.boot, n_ranks)) return 1;
+    for (int r = 0; r < n_ranks; ++r)
+      if (r != rank && hipIpcOpenMemHandle((void **)&c.box[r], c.boot->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return 1;
+    c.peer = true; c.ready = true;
+    return boot_barrier(c.boot, n_ranks);
   }
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof id);
@@ -166,85 +181,190 @@ inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
 }
 
 inline void comm_destroy(Comm &c) {
-  if (c.ready && c.shm) {
-    if (c.rank == 0) (void)shm_unlink(c.shm_name);
-    (void)munmap(c.hdr, c.map_bytes);
+  if (c.ready && c.peer) {
+    (void)hipDeviceSynchronize();
+    (void)boot_barrier(c.boot, c.n_ranks);  // nobody unmaps a mailbox a peer may still write to
+    for (int r = 0; r < c.n_ranks; ++r)
+      if (r != c.rank && c.box[r]) (void)hipIpcCloseMemHandle(c.box[r]);
+    (void)boot_barrier(c.boot, c.n_ranks);
+    if (c.box[c.rank]) (void)hipFree(c.box[c.rank]);
+    if (c.cnt) (void)hipFree(c.cnt);
+    if (c.abort_host) (void)hipHostFree(c.abort_host);
+    if (c.rank == 0) (void)shm_unlink(c.boot_name);
+    (void)munmap(c.boot, sizeof(PeerBoot));
   } else if (c.ready && c.comm) {
     (void)ncclCommDestroy(c.comm);
   }
   c = Comm();
 }
 
-// ---- shared-memory transport: device -> own slot, barrier, peers' slots -> device, barrier
-inline int shm_halo_exchange(Comm &c, const HaloPlan &h, double *x, int64_t n_owned, hipStream_t stream) {
-  if ((int64_t)sizeof(double) * h.total_send > c.hdr->slot_bytes) return 1;
-  for (int r = 0; r < c.n_ranks; ++r) c.hdr->seg_cnt[c.rank][r] = 0;
-  int64_t so = 0;
-  for (int i = 0; i < h.n_neighbors; ++i) {
-    c.hdr->seg_off[c.rank][h.rank[(size_t)i]] = so;
-    c.hdr->seg_cnt[c.rank][h.rank[(size_t)i]] = h.send_count[(size_t)i];
-    so += h.send_count[(size_t)i];
-  }
-  if (h.total_send > 0 &&
-      hipMemcpyAsync(c.slot(c.rank), h.send_buf, sizeof(double) * (size_t)h.total_send, hipMemcpyDeviceToHost, stream) != hipSuccess)
-    return 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  if (shm_barrier(c)) return 1;
-  int64_t ro = 0;
-  for (int i = 0; i < h.n_neighbors; ++i) {
-    const int peer = h.rank[(size_t)i];
-    const int64_t cnt = h.recv_count[(size_t)i];
-    if (cnt > 0) {
-      if (c.hdr->seg_cnt[peer][c.rank] != cnt) return 1;  // the two halo plans disagree
-      if (hipMemcpyAsync(x + n_owned + ro, c.slot(peer) + c.hdr->seg_off[peer][c.rank], sizeof(double) * (size_t)cnt,
-                         hipMemcpyHostToDevice, stream) != hipSuccess)
-        return 1;
+// ---------------------------------------------------------------- peer transport: kernels
+
+struct PeerSendArgs {
+  char *peer_box[kPeerMaxRanks];       // mailbox of the i-th destination
+  const double *src[kPeerMaxRanks];
+  long long count[kPeerMaxRanks];      // doubles
+  unsigned long long wait_ack[kPeerMaxRanks];  // round whose acknowledgement frees the buffer (0: none)
+  int dst_rank[kPeerMaxRanks];
+  int n, me, n_ranks;
+  unsigned long long seq;
+  long long cap;
+  char *my_box;
+  unsigned int *cnt;
+  int *abort_flag;
+};
+
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// true when *flag >= want arrived in time; false (and the abort flag raised / seen) otherwise.  One thread polls.
+__device__ __forceinline__ bool peer_wait(const unsigned long long *flag, unsigned long long want, int *abort_flag) {
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    for (long long spins = 0; sys_load(flag) < want; ++spins) {
+      if ((spins & 1023) == 1023 && *(volatile int *)abort_flag) { ok = 0; break; }
+      if (spins > kPeerSpinLimit) { *abort_flag = 1; ok = 0; break; }
     }
-    ro += cnt;
+    ok_s = ok;
   }
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  return shm_barrier(c);
+  __syncthreads();
+  const bool ok = ok_s != 0;
+  __syncthreads();  // (the flag may be rewritten by the next wait)
+  return ok;
 }
 
-inline int shm_allreduce(Comm &c, double *dev, int count, bool max_op, hipStream_t stream) {
-  if (count > 64) return 1;
-  double mine[64], acc[64];
-  if (hipMemcpyAsync(mine, dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  std::memcpy(c.slot(c.rank), mine, sizeof(double) * (size_t)count);
-  if (shm_barrier(c)) return 1;
-  for (int k = 0; k < count; ++k) {  // rank order: the same result on every rank
-    double a = c.slot(0)[k];
-    for (int r = 1; r < c.n_ranks; ++r) {
-      const double v = c.slot(r)[k];
-      a = max_op ? (v > a ? v : a) : a + v;
-    }
-    acc[k] = a;
+// grid (G, n): workgroups (.., i) copy src[i] into destination i's mailbox (payload[seq & 1][me]); the last one publishes seq
+__global__ __launch_bounds__(kThreads) void peer_send_kernel(PeerSendArgs a) {
+  const int i = blockIdx.y;
+  if (*(volatile int *)a.abort_flag) return;
+  if (a.wait_ack[i]) {
+    const unsigned long long *ack = reinterpret_cast<const unsigned long long *>(a.my_box + 2048 + a.dst_rank[i] * 128);
+    if (!peer_wait(ack, a.wait_ack[i], a.abort_flag)) return;
   }
-  if (hipMemcpyAsync(dev, acc, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  return shm_barrier(c);
+  double *dst = reinterpret_cast<double *>(a.peer_box[i] + kPeerFlagBytes + ((long long)(a.seq & 1) * a.n_ranks + a.me) * a.cap);
+  const double *src = a.src[i];
+  for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < a.count[i]; k += (long long)gridDim.x * kThreads) dst[k] = src[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&a.cnt[i], 1u) == gridDim.x - 1) {
+    a.cnt[i] = 0;
+    sys_store(reinterpret_cast<unsigned long long *>(a.peer_box[i] + a.me * 128), a.seq);
+  }
 }
 
-// full[r * chunk ...) <- rank r's chunk (own chunk already in place)
-inline int shm_allgather(Comm &c, double *full, int64_t chunk, hipStream_t stream) {
-  if ((int64_t)sizeof(double) * chunk > c.hdr->slot_bytes) return 1;
-  if (hipMemcpyAsync(c.slot(c.rank), full + (int64_t)c.rank * chunk, sizeof(double) * (size_t)chunk, hipMemcpyDeviceToHost, stream) !=
-      hipSuccess)
-    return 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  if (shm_barrier(c)) return 1;
-  for (int r = 0; r < c.n_ranks; ++r)
-    if (r != c.rank && hipMemcpyAsync(full + (int64_t)r * chunk, c.slot(r), sizeof(double) * (size_t)chunk, hipMemcpyHostToDevice,
-                                      stream) != hipSuccess)
-      return 1;
-  if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-  return shm_barrier(c);
+struct PeerRecvArgs {
+  char *peer_box[kPeerMaxRanks];   // mailbox of the i-th source (for the acknowledgement)
+  double *dst[kPeerMaxRanks];
+  long long count[kPeerMaxRanks];
+  int src_rank[kPeerMaxRanks];
+  int n, me, n_ranks;
+  unsigned long long seq;
+  long long cap;
+  char *my_box;
+  unsigned int *cnt;
+  int *abort_flag;
+};
+
+// grid (G, n): wait for source i's round seq, unpack its payload, the last workgroup acknowledges
+__global__ __launch_bounds__(kThreads) void peer_recv_kernel(PeerRecvArgs a) {
+  const int i = blockIdx.y;
+  if (*(volatile int *)a.abort_flag) return;
+  const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(a.my_box + a.src_rank[i] * 128);
+  if (!peer_wait(flag, a.seq, a.abort_flag)) return;
+  const double *src = reinterpret_cast<const double *>(a.my_box + kPeerFlagBytes + ((long long)(a.seq & 1) * a.n_ranks + a.src_rank[i]) * a.cap);
+  double *dst = a.dst[i];
+  for (long long k = (long long)blockIdx.x * kThreads + threadIdx.x; k < a.count[i]; k += (long long)gridDim.x * kThreads)
+    dst[k] = __builtin_nontemporal_load(src + k);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&a.cnt[kPeerMaxRanks + i], 1u) == gridDim.x - 1) {
+    a.cnt[kPeerMaxRanks + i] = 0;
+    sys_store(reinterpret_cast<unsigned long long *>(a.peer_box[i] + 2048 + a.me * 128), a.seq);
+  }
 }
+
+// one workgroup: dev[k] = reduction over the ranks, in rank order (every rank gets the same bits), of the values the
+// peers sent (payload[seq & 1][r][k]) and the rank's own dev[k]; acknowledges every peer
+__global__ __launch_bounds__(kThreads) void peer_allreduce_kernel(PeerRecvArgs a, double *dev, int count, int max_op) {
+  if (*(volatile int *)a.abort_flag) return;
+  for (int i = 0; i < a.n; ++i) {
+    const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(a.my_box + a.src_rank[i] * 128);
+    if (!peer_wait(flag, a.seq, a.abort_flag)) return;
+  }
+  if ((int)threadIdx.x < count) {
+    double acc = 0.0;
+    for (int r = 0; r < a.n_ranks; ++r) {
+      double v;
+      if (r == a.me) v = dev[threadIdx.x];
+      else v = __builtin_nontemporal_load(reinterpret_cast<const double *>(a.my_box + kPeerFlagBytes + ((long long)(a.seq & 1) * a.n_ranks + r) * a.cap) + threadIdx.x);
+      acc = r == 0 ? v : (max_op ? (v > acc ? v : acc) : acc + v);
+    }
+    dev[threadIdx.x] = acc;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < a.n; ++i) sys_store(reinterpret_cast<unsigned long long *>(a.peer_box[i] + 2048 + a.me * 128), a.seq);
+}
+
+// ---------------------------------------------------------------- peer transport: host side
+
+struct PeerMsg { int peer; const double *src; double *dst; int64_t send_count, recv_count; };
+
+inline int peer_grid(int64_t count) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (count + 4095) / 4096)); }
+
+// one round: send msgs[i].src (send_count doubles) to msgs[i].peer and receive recv_count doubles from it into msgs[i].dst
+// (either count may be 0).  Every rank calls the collectives in the same order, so the round number needs no negotiation.
+inline int peer_exchange(Comm &c, const std::vector<PeerMsg> &msgs, hipStream_t stream, bool unpack = true) {
+  const unsigned long long seq = ++c.seq;
+  PeerSendArgs s{};
+  PeerRecvArgs r{};
+  int max_send_grid = 1, max_recv_grid = 1;
+  for (const PeerMsg &m : msgs) {
+    if ((int64_t)sizeof(double) * std::max(m.send_count, m.recv_count) > c.cap) return 1;  // GMG_PEER_SLOT_MB too small
+    if (m.send_count > 0) {
+      const int i = s.n++;
+      s.peer_box[i] = c.box[m.peer]; s.src[i] = m.src; s.count[i] = m.send_count; s.dst_rank[i] = m.peer;
+      s.wait_ack[i] = c.last_sent[m.peer][seq & 1];
+      c.last_sent[m.peer][seq & 1] = seq;
+      max_send_grid = std::max(max_send_grid, peer_grid(m.send_count));
+    }
+    if (m.recv_count > 0) {
+      const int i = r.n++;
+      r.peer_box[i] = c.box[m.peer]; r.dst[i] = m.dst; r.count[i] = m.recv_count; r.src_rank[i] = m.peer;
+      max_recv_grid = std::max(max_recv_grid, peer_grid(m.recv_count));
+    }
+  }
+  s.me = r.me = c.rank; s.n_ranks = r.n_ranks = c.n_ranks; s.seq = r.seq = seq; s.cap = r.cap = c.cap;
+  s.my_box = r.my_box = c.box[c.rank]; s.cnt = r.cnt = c.cnt; s.abort_flag = r.abort_flag = c.abort_host;
+  if (s.n) hipLaunchKernelGGL(peer_send_kernel, dim3(max_send_grid, s.n), dim3(kThreads), 0, stream, s);
+  if (r.n && unpack) hipLaunchKernelGGL(peer_recv_kernel, dim3(max_recv_grid, r.n), dim3(kThreads), 0, stream, r);
+  return hipGetLastError() != hipSuccess;
+}
+
+inline int peer_allreduce(Comm &c, double *dev, int count, bool max_op, hipStream_t stream) {
+  if (count > kThreads) return 1;
+  std::vector<PeerMsg> msgs;
+  for (int p = 0; p < c.n_ranks; ++p)
+    if (p != c.rank) msgs.push_back(PeerMsg{p, dev, nullptr, count, count});
+  if (peer_exchange(c, msgs, stream, false)) return 1;  // sends only; the reduce kernel below receives
+  PeerRecvArgs r{};
+  for (const PeerMsg &m : msgs) { const int i = r.n++; r.peer_box[i] = c.box[m.peer]; r.src_rank[i] = m.peer; }
+  r.me = c.rank; r.n_ranks = c.n_ranks; r.seq = c.seq; r.cap = c.cap; r.my_box = c.box[c.rank]; r.cnt = c.cnt; r.abort_flag = c.abort_host;
+  // the peers' copies of MY value leave from dev before the reduce kernel overwrites it: same stream, in order
+  hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(kThreads), 0, stream, r, dev, count, max_op ? 1 : 0);
+  return hipGetLastError() != hipSuccess;
+}
+
+// ---------------------------------------------------------------- the four calls
 
 // x[n_owned ...] <- neighbours' owned values; all traffic on `stream`.
 inline int halo_exchange(Comm &c, const HaloPlan &h, double *x, int64_t n_owned, hipStream_t stream) {
-  if (h.n_neighbors == 0) return 0;
+  if (h.n_neighbors == 0 && !c.peer) return 0;
   if (!c.ready) return 1;
   if (h.total_send > 0) {
     int64_t g = (h.total_send + kThreads - 1) / kThreads;
@@ -252,7 +372,16 @@ inline int halo_exchange(Comm &c, const HaloPlan &h, double *x, int64_t n_owned,
     hipLaunchKernelGGL(gather_scatter_kernel, dim3((unsigned)g), dim3(kThreads), 0, stream, h.send_buf, (const int32_t *)nullptr,
                        (const double *)x, (const int32_t *)h.send_idx, h.total_send);
   }
-  if (c.shm) return shm_halo_exchange(c, h, x, n_owned, stream);
+  if (c.peer) {  // (a rank without neighbours still takes part in the round: the round numbers stay in step)
+    std::vector<PeerMsg> msgs;
+    int64_t so = 0, ro = 0;
+    for (int i = 0; i < h.n_neighbors; ++i) {
+      msgs.push_back(PeerMsg{h.rank[(size_t)i], h.send_buf + so, x + n_owned + ro, h.send_count[(size_t)i], h.recv_count[(size_t)i]});
+      so += h.send_count[(size_t)i];
+      ro += h.recv_count[(size_t)i];
+    }
+    return peer_exchange(c, msgs, stream);
+  }
   if (ncclGroupStart() != ncclSuccess) return 1;
   int64_t so = 0, ro = 0;
   bool failed = false;
@@ -270,13 +399,27 @@ inline int halo_exchange(Comm &c, const HaloPlan &h, double *x, int64_t n_owned,
 
 inline int allreduce_sum(Comm &c, double *dev, int count, hipStream_t stream) {
   if (!c.ready) return 1;
-  if (c.shm) return shm_allreduce(c, dev, count, false, stream);
+  if (c.peer) return peer_allreduce(c, dev, count, false, stream);
   return ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, c.comm, stream) != ncclSuccess;
 }
 inline int allreduce_max(Comm &c, double *dev, int count, hipStream_t stream) {
   if (!c.ready) return 1;
-  if (c.shm) return shm_allreduce(c, dev, count, true, stream);
+  if (c.peer) return peer_allreduce(c, dev, count, true, stream);
   return ncclAllReduce(dev, dev, (size_t)count, ncclDouble, ncclMax, c.comm, stream) != ncclSuccess;
 }
+
+// full[r * chunk ...) <- rank r's chunk (own chunk already in place), for every r
+inline int allgather_chunks(Comm &c, double *full, int64_t chunk, hipStream_t stream) {
+  if (!c.ready) return 1;
+  if (c.peer) {
+    std::vector<PeerMsg> msgs;
+    for (int p = 0; p < c.n_ranks; ++p)
+      if (p != c.rank) msgs.push_back(PeerMsg{p, full + (int64_t)c.rank * chunk, full + (int64_t)p * chunk, chunk, chunk});
+    return peer_exchange(c, msgs, stream);
+  }
+  return ncclAllGather(full + (int64_t)c.rank * chunk, full, (size_t)chunk, ncclDouble, c.comm, stream) != ncclSuccess;
+}
+
+inline bool comm_aborted(const Comm &c) { return c.peer && c.abort_host && *c.abort_host != 0; }
 
 }  // namespace gmg

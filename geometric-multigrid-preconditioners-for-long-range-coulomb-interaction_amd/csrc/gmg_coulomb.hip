@@ -677,7 +677,7 @@ SpmvArgs base_args(const DevCSR &m, const double *x, double *y) {
 
 // ghost import of `x` for operator m (Epetra_Import inside every vmult); no-op on one rank
 int import_ghosts(gmg_context *ctx, const DevCSR &m, double *x) {
-  if (m.halo.n_neighbors == 0) return GMG_OK;
+  if (!m.halo.active) return GMG_OK;  // a replicated operator
   int rc = halo_exchange(ctx->comm, m.halo, x, m.n_rows, ctx->stream);
   if (rc) return fail(ctx, GMG_ERR_COMM, "halo exchange failed");
   return GMG_OK;
@@ -704,6 +704,7 @@ int fetch_scalars(gmg_context *ctx, int n) {
   HIPC(hipMemcpyAsync(ctx->scal_host, ctx->scal_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   HIPC(stream_wait(ctx->stream));
   if (*ctx->sgs_abort) return fail(ctx, GMG_ERR_HIP, "SSOR sweep: a wave gave up waiting for its partner (internal protocol error)");
+  if (comm_aborted(ctx->comm)) return fail(ctx, GMG_ERR_COMM, "peer transport: a rank gave up waiting for a message or an acknowledgement");
   if (ctx->comm.n_ranks > 1) {
     // sums: slots flagged by the caller; handled in the callers below
   }
@@ -793,11 +794,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
       piece(ctx->comm.rank, &b, &e);
       double *mine = L.sgs.w_stage + (int64_t)ctx->comm.rank * len;
       if (e > b) HIPC(hipMemcpyAsync(mine, y + b, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
-      if (ctx->comm.shm) {
-        if (shm_allgather(ctx->comm, L.sgs.w_stage, len, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "SSOR: all-gather (shared memory) failed");
-      } else if (ncclAllGather(mine, L.sgs.w_stage, (size_t)len, ncclDouble, ctx->comm.comm, ctx->stream) != ncclSuccess) {
-        return fail(ctx, GMG_ERR_COMM, "SSOR: all-gather failed");
-      }
+      if (allgather_chunks(ctx->comm, L.sgs.w_stage, len, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "SSOR: all-gather failed");
       for (int r = 0; r < n_ranks; ++r) {
         if (r == ctx->comm.rank) continue;
         piece(r, &b, &e);
@@ -1026,12 +1023,7 @@ int allgather_full(gmg_context *ctx, double *full, const double *local, int64_t 
   part_range(n_global, ctx->comm.rank, ctx->comm.n_ranks, &b, &e);
   // stage the owned slice at its place; the padded tail of the last chunks is never read
   if (e > b) HIPC(hipMemcpyAsync(full + b, local, sizeof(double) * (size_t)(e - b), hipMemcpyDeviceToDevice, ctx->stream));
-  if (ctx->comm.shm) {
-    if (shm_allgather(ctx->comm, full, c, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-gather (shared memory) failed");
-    return GMG_OK;
-  }
-  if (ncclAllGather(full + (int64_t)ctx->comm.rank * c, full, (size_t)c, ncclDouble, ctx->comm.comm, ctx->stream) != ncclSuccess)
-    return fail(ctx, GMG_ERR_COMM, "all-gather failed");
+  if (allgather_chunks(ctx->comm, full, c, ctx->stream)) return fail(ctx, GMG_ERR_COMM, "all-gather failed");
   return GMG_OK;
 }
 
@@ -1839,7 +1831,7 @@ int gmg_spmv(gmg_context *ctx, int which, double *dst, const double *src) {
   if (!ctx) return GMG_ERR_INVALID;
   DevCSR *m = which_matrix(ctx, which);
   if (!m || !m->valid) return fail(ctx, GMG_ERR_INVALID, "gmg_spmv: operator not set");
-  if (m->halo.n_neighbors > 0) {
+  if (m->halo.active) {
     // the caller's src holds owned entries only: stage it in a buffer with a ghost tail
     double *tmp = (which == GMG_SYSTEM) ? ctx->S_tmp : ctx->lv[(size_t)which].w3;
     HIPC(hipMemcpyAsync(tmp, src, sizeof(double) * (size_t)m->n_rows, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1888,7 +1880,7 @@ int gmg_prolongate(gmg_context *ctx, int level, double *dst_fine, const double *
   if (!ctx || level < 0 || level >= ctx->n_levels - 1) return GMG_ERR_INVALID;
   Level &L = ctx->lv[(size_t)level];
   if (!L.has_P) return fail(ctx, GMG_ERR_INVALID, "prolongation not set");
-  if (L.P.halo.n_neighbors > 0) {
+  if (L.P.halo.active) {
     HIPC(hipMemcpyAsync(L.w3, src_coarse, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice, ctx->stream));
     CHK(import_ghosts(ctx, L.P, L.w3));
     return spmv(ctx, L.P, kStore, L.w3, dst_fine);
@@ -1900,7 +1892,7 @@ int gmg_restrict_and_add(gmg_context *ctx, int level, double *dst_coarse, const 
   if (!ctx || level < 0 || level >= ctx->n_levels - 1) return GMG_ERR_INVALID;
   Level &L = ctx->lv[(size_t)level];
   if (!L.has_P) return fail(ctx, GMG_ERR_INVALID, "prolongation not set");
-  if (L.Pt.halo.n_neighbors > 0) {
+  if (L.Pt.halo.active) {
     Level &F = ctx->lv[(size_t)level + 1];
     HIPC(hipMemcpyAsync(F.w3, src_fine, sizeof(double) * (size_t)F.n, hipMemcpyDeviceToDevice, ctx->stream));
     CHK(import_ghosts(ctx, L.Pt, F.w3));

@@ -141,9 +141,12 @@ int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo,
 
 /* ---- distributed (one process per GPU, RCCL over xGMI) ------------------------------ */
 #define GMG_UNIQUE_ID_BYTES 128
-int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broadcast by the host; with GMG_COMM_TRANSPORT=shm
-                                                             * in the environment the id names a host-staged shared-memory
-                                                             * transport for ranks of one node (tests: several ranks on one GPU) */
+int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broadcast by the host.  Default: an RCCL id.  With
+                                                             * GMG_COMM_TRANSPORT=peer in the environment the id names the
+                                                             * peer-to-peer transport for the GPUs of one node (mailboxes mapped
+                                                             * with hipIpc, messages written by kernels straight into the peer's
+                                                             * HBM, flags instead of collectives); it also works between
+                                                             * processes sharing one GPU (tests)                              */
 int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
 /* Distributed layout: the system matrix / outer-CG vectors and level 0 (matrix,
  * coarse CG) are row-partitioned in equal chunks -- gmg_partition_range gives the canonical

@@ -1,7 +1,7 @@
 """Two ranks on ONE GPU: the rank-parallel layout end to end.
 
 RCCL refuses two ranks on the same device, so the ranks talk through the library's host-staged
-shared-memory transport (GMG_COMM_TRANSPORT=shm, csrc/gmg_comm.hpp) -- same partition, same halo
+shared-memory transport (GMG_COMM_TRANSPORT=peer, csrc/gmg_comm.hpp) -- same partition, same halo
 plans, same pack / unpack kernels, same distributed coarse CG and V-cycle all-gathers as over
 RCCL; only the bytes travel differently.  Checked against the reference's printed numbers (the
 reductions are summed in a different order than on one rank, hence 1e-9 instead of 11 digits
@@ -24,11 +24,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def run_ranks(n_ranks, golden_dir, tmp_path, monkeypatch, nacl=0, env_extra=None, part="always", blocks=1):
     """n_ranks = 0: one plain process without a communicator (the single-GPU layout)"""
-    monkeypatch.setenv("GMG_COMM_TRANSPORT", "shm")
-    monkeypatch.setenv("GMG_SHM_SLOT_MB", "8")
+    monkeypatch.setenv("GMG_COMM_TRANSPORT", "peer")
+    monkeypatch.setenv("GMG_PEER_SLOT_MB", "16")
     uid = capi().Context.unique_id()
-    assert uid.startswith(b"GMGSHM:")
-    name = uid[len(b"GMGSHM:"):].split(b"\0")[0].decode()
+    assert uid.startswith(b"GMGPEER:")
+    name = uid[len(b"GMGPEER:"):].split(b"\0")[0].decode()
     env = dict(os.environ)
     env.update(env_extra or {})
     outs = [str(tmp_path / f"n{n_ranks}_{part}_b{blocks}_rank{r}.json") for r in range(max(1, n_ranks))]

@@ -4,12 +4,12 @@ import os, sys, json, subprocess, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
-os.environ["GMG_COMM_TRANSPORT"] = "shm"; os.environ["GMG_SHM_SLOT_MB"] = "64"
+os.environ["GMG_COMM_TRANSPORT"] = "peer"; os.environ["GMG_PEER_SLOT_MB"] = "64"
 from gpu_util import capi
 HERE = os.path.join(ROOT, "tests")
 def run(n_ranks, nacl, part):
     uid = capi().Context.unique_id()
-    name = uid[len(b"GMGSHM:"):].split(b"\0")[0].decode()
+    name = uid[len(b"GMGPEER:"):].split(b"\0")[0].decode()
     d = tempfile.mkdtemp()
     outs = [os.path.join(d, f"r{r}.json") for r in range(max(1, n_ranks))]
     ps = [subprocess.Popen([sys.executable, os.path.join(HERE, "two_rank_worker.py"), str(r), str(n_ranks), uid.hex(), os.path.join(HERE, "golden"), outs[r], str(nacl), part]) for r in range(max(1, n_ranks))]
