@@ -37,14 +37,18 @@ namespace gmg {
 
 constexpr int kPeerMaxRanks = 8;
 constexpr char kPeerTag[] = "GMGPEER:";
-constexpr int64_t kPeerFlagBytes = 4096;            // head of a mailbox: data_seq[src] at src * 128, ack_seq[dst] at 2048 + dst * 128
-constexpr long long kPeerSpinLimit = 400000000LL;   // polls (~1 s) after which a waiting kernel declares the exchange broken
+constexpr int64_t kPeerFlagBytes = 16384;           // head of a mailbox: data_seq[src] at src * 128, ack_seq[dst] at 2048 + dst * 128;
+                                                    // from kPeerCgOffset (4096): sums and halo tags of the coarse CG (gmg_device.hpp: PeerCG)
+constexpr long long kPeerSpinLimit = 30000000LL;    // polls (~0.5 us each with a short sleep: ~15 s) after which a waiting kernel declares the exchange broken.
+                                                    // The ranks meet on the host (comm_host_barrier) before a solve, so a kernel never waits out a peer's host work.
 
 // start-up only: a POSIX shared-memory object carries the IPC handles and a host barrier
 struct PeerBoot {  // zero-filled by ftruncate
   std::atomic<int> arrived, generation;
   int64_t cap_bytes;  // payload capacity per (parity, source)
   hipIpcMemHandle_t handle[kPeerMaxRanks];
+  hipIpcMemHandle_t shared_handle[kPeerMaxRanks];  // comm_share_alloc: one collective allocation at a time
+  int64_t meta[kPeerMaxRanks][4 + kPeerMaxRanks];  // comm_exchange_meta
 };
 
 struct Comm {
@@ -225,10 +229,13 @@ __device__ __forceinline__ bool peer_wait(const unsigned long long *flag, unsign
   __shared__ int ok_s;
   if (threadIdx.x == 0) {
     int ok = 1;
-    for (long long spins = 0; sys_load(flag) < want; ++spins) {
-      if ((spins & 1023) == 1023 && *(volatile int *)abort_flag) { ok = 0; break; }
+    // relaxed polls (an acquire load would invalidate the caches on every poll); one acquire fence at the end
+    for (long long spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want; ++spins) {
+      __builtin_amdgcn_s_sleep(4);
+      if ((spins & 255) == 255 && *(volatile int *)abort_flag) { ok = 0; break; }
       if (spins > kPeerSpinLimit) { *abort_flag = 1; ok = 0; break; }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     ok_s = ok;
   }
   __syncthreads();
@@ -418,6 +425,47 @@ inline int allgather_chunks(Comm &c, double *full, int64_t chunk, hipStream_t st
     return peer_exchange(c, msgs, stream);
   }
   return ncclAllGather(full + (int64_t)c.rank * chunk, full, (size_t)chunk, ncclDouble, c.comm, stream) != ncclSuccess;
+}
+
+// Collective: every rank allocates `bytes` of device memory and maps everybody else's allocation (the coarse CG keeps
+// its direction vectors there: the neighbours write their halo entries straight into them).  local[rank] is the own one.
+inline int comm_share_alloc(Comm &c, size_t bytes, char *ptrs[kPeerMaxRanks]) {
+  if (!c.peer) return 1;
+  for (int r = 0; r < kPeerMaxRanks; ++r) ptrs[r] = nullptr;
+  if (hipMalloc((void **)&ptrs[c.rank], bytes) != hipSuccess) return 1;
+  if (hipMemset(ptrs[c.rank], 0, bytes) != hipSuccess) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipIpcGetMemHandle(&c.boot->shared_handle[c.rank], ptrs[c.rank]) != hipSuccess) return 1;
+  if (boot_barrier(c.boot, c.n_ranks)) return 1;
+  for (int r = 0; r < c.n_ranks; ++r)
+    if (r != c.rank && hipIpcOpenMemHandle((void **)&ptrs[r], c.boot->shared_handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return 1;
+  return boot_barrier(c.boot, c.n_ranks);  // (the handle table may be reused after this)
+}
+inline void comm_share_free(Comm &c, char *ptrs[kPeerMaxRanks]) {
+  if (!c.peer || !ptrs[c.rank]) return;
+  (void)hipDeviceSynchronize();
+  (void)boot_barrier(c.boot, c.n_ranks);  // nobody still writes into a vector about to be unmapped
+  for (int r = 0; r < c.n_ranks; ++r)
+    if (r != c.rank && ptrs[r]) (void)hipIpcCloseMemHandle(ptrs[r]);
+  (void)boot_barrier(c.boot, c.n_ranks);
+  (void)hipFree(ptrs[c.rank]);
+  for (int r = 0; r < kPeerMaxRanks; ++r) ptrs[r] = nullptr;
+}
+// Collective: every rank publishes a few integers, everybody reads everybody's.
+inline int comm_exchange_meta(Comm &c, const int64_t *mine, int n, int64_t all[kPeerMaxRanks][4 + kPeerMaxRanks]) {
+  if (!c.peer || n > 4 + kPeerMaxRanks) return 1;
+  for (int k = 0; k < n; ++k) c.boot->meta[c.rank][k] = mine[k];
+  if (boot_barrier(c.boot, c.n_ranks)) return 1;
+  for (int r = 0; r < c.n_ranks; ++r)
+    for (int k = 0; k < n; ++k) all[r][k] = c.boot->meta[r][k];
+  return boot_barrier(c.boot, c.n_ranks);
+}
+
+// The ranks meet on the host: called before a solve, so that a rank that finished its host-side setup early does not
+// park a waiting kernel on its GPU for seconds.  (RCCL: its collectives are enqueued, not spun on: nothing to do.)
+inline int comm_host_barrier(Comm &c) {
+  if (!c.ready || !c.peer) return 0;
+  return boot_barrier(c.boot, c.n_ranks);
 }
 
 inline bool comm_aborted(const Comm &c) { return c.peer && c.abort_host && *c.abort_host != 0; }

@@ -117,6 +117,12 @@ struct gmg_context {
   double *cg_g = nullptr, *cg_d0 = nullptr, *cg_d1 = nullptr, *cg_h = nullptr;
   double *cg_ring[kXRing] = {};  // direction vectors of the last kXRing iterations (three-kernel coarse CG), allocated on first use
   int64_t cg_ring_len = 0;
+  // peer transport, partitioned level 0: the ring is one shared allocation the neighbours write their halo entries into
+  char *ring_shared[kPeerMaxRanks] = {};
+  int64_t ring_stride = 0;                      // doubles between my ring slots
+  int64_t peer_meta[kPeerMaxRanks][4 + kPeerMaxRanks] = {};  // per rank: ring stride, owned rows, ghost offset of every source
+  unsigned long long peer_tag0 = 1;             // tags of the next coarse solve start here
+  unsigned int *peer_push_cnt = nullptr;
   CGState *st = nullptr;       // device
   CGState *st_host = nullptr;  // pinned, 2 slots (the chunk being checked / the speculative one)
   CGState st_final{};
@@ -937,7 +943,9 @@ int run_cg_chunks(gmg_context *ctx, int later_default, EnqueueOne enqueue_one) {
   };
   int slot = 0;
   CHK(launch_chunk(std::min(first, maxit + 1), slot));
-  const bool speculate = !l0_partitioned(ctx);  // no-op iterations still exchange halos / all-reduce: not worth it across ranks
+  // over RCCL the no-op iterations after convergence would still run their collectives: not worth it across ranks; over
+  // the peer transport they return at once like on one GPU
+  const bool speculate = !l0_partitioned(ctx) || ctx->comm.peer;
   for (;;) {
     if (speculate) CHK(launch_chunk(later, slot ^ 1));
     for (;;) {
@@ -1489,6 +1497,10 @@ int setup_sgs(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const in
 
 // frees every operator / work vector but keeps the stream, the reduction scratch and the communicator
 void free_cg_ring(gmg_context *ctx) {
+  if (ctx->ring_shared[ctx->comm.rank]) {  // (collective: every rank frees its ring at the same point, gmg_set_level_matrix / gmg_reset / gmg_destroy)
+    comm_share_free(ctx->comm, ctx->ring_shared);
+    for (double *&p : ctx->cg_ring) p = nullptr;
+  }
   for (double *&p : ctx->cg_ring)
     if (p) { (void)hipFree(p); p = nullptr; }
   ctx->cg_ring_len = 0;
@@ -1575,8 +1587,9 @@ int gmg_destroy(gmg_context *ctx) {
   if (!ctx) return GMG_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  release_operators(ctx);  // (before the communicator: the shared direction vectors are unmapped collectively)
+  if (ctx->peer_push_cnt) (void)hipFree(ctx->peer_push_cnt);
   comm_destroy(ctx->comm);
-  release_operators(ctx);
   for (double *p : {ctx->part_a, ctx->part_b, ctx->scal_dev})
     if (p) (void)hipFree(p);
   if (ctx->st) (void)hipFree(ctx->st);
@@ -2054,6 +2067,14 @@ int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id) {
   (void)hipSetDevice(ctx->device);
   if (comm_init(ctx->comm, rank, n_ranks, id)) return fail(ctx, GMG_ERR_COMM, "ncclCommInitRank failed");
   ctx->dist = true;
+  return GMG_OK;
+}
+
+int gmg_comm_barrier(gmg_context *ctx) {
+  if (!ctx) return GMG_ERR_INVALID;
+  if (!ctx->dist) return GMG_OK;
+  HIPC(hipStreamSynchronize(ctx->stream));
+  if (comm_host_barrier(ctx->comm)) return fail(ctx, GMG_ERR_COMM, "host barrier: a rank did not arrive");
   return GMG_OK;
 }
 

@@ -82,6 +82,58 @@ struct CGState {
   double alpha[kXRing];  // step lengths of the last kXRing iterations (slot = iteration % kXRing), three-kernel variant
 };
 
+// ---------------------------------------------------------------- coarse CG over the peer transport (several ranks)
+// With a row-partitioned level 0 an iteration needs the ghost entries of d and two global sums.  Over the peer
+// transport (gmg_comm.hpp) none of them is a collective: the direction kernel stores the entries its neighbours need
+// straight into THEIR direction vectors and publishes a tag; each sum is ONE one-workgroup kernel (this rank's sum of
+// the partials -> every rank's slot -> wait for everybody's tags -> the total, added in rank order: the same bits on
+// every rank); a one-workgroup kernel waits for the neighbours' halo tags in front of the SpMV.  The big kernels never
+// wait (a grid that fills the GPU and spins would starve the producer when several ranks share one GPU, as in the
+// tests).  Everything is indexed by the iteration number modulo 8 and tagged tag0 + iteration: the ranks run in
+// lockstep (every iteration needs everybody's sums), so a slot written 8 iterations ago has long been read.
+//   area (my mailbox + kPeerCgOffset):  [kind 0 = |g|^2, 1 = d.h][slot 8] { double val[8]; u64 tag[8] }   (2 KB)
+//                                       + 2048: halo tags [slot 8][src 8] u64
+constexpr int kPeerRanks = 8;
+constexpr int kPeerCgOffset = 4096;
+struct PeerCG {
+  char *area;                   // nullptr: single GPU, or the RCCL path
+  char *peer_area[kPeerRanks];  // the same area of every rank (peer_area[me] == area)
+  int n_ranks, me;
+  unsigned nb_mask;             // ranks whose halo entries I receive
+  unsigned long long tag0;      // of this solve
+  int *abort_flag;
+};
+constexpr long long kPeerCgSpinLimit = 30000000LL;  // polls of ~0.5 us with a short sleep: ~15 s (inside a solve the ranks are microseconds apart)
+
+// all ranks' tags of (kind, iteration) have arrived (one thread polls, bounded); false: the exchange is broken
+__device__ __forceinline__ bool peer_cg_wait(const PeerCG &pc, const unsigned long long *tags, unsigned mask, unsigned long long want) {
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    for (int r = 0; r < pc.n_ranks && ok; ++r) {
+      if (!((mask >> r) & 1u)) continue;
+      // relaxed polls (an acquire load would invalidate the caches on every poll); one acquire fence once all tags are in
+      for (long long spins = 0; __hip_atomic_load(tags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want; ++spins) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((spins & 255) == 255 && *(volatile int *)pc.abort_flag) { ok = 0; break; }
+        if (spins > kPeerCgSpinLimit) { *pc.abort_flag = 1; ok = 0; break; }
+      }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (system scope: the default of the builtin)
+    ok_s = ok;
+  }
+  __syncthreads();
+  const bool ok = ok_s != 0;
+  __syncthreads();
+  return ok;
+}
+__device__ __forceinline__ const double *peer_cg_vals(const PeerCG &pc, int kind, int it) {
+  return reinterpret_cast<const double *>(pc.area + (kind * 8 + (it & 7)) * 128);
+}
+__device__ __forceinline__ const unsigned long long *peer_cg_tags(const PeerCG &pc, int kind, int it) {
+  return reinterpret_cast<const unsigned long long *>(pc.area + (kind * 8 + (it & 7)) * 128 + 64);
+}
+
 // ---------------------------------------------------------------- CSR SpMV with LDS row window
 
 enum SpmvMode : int {
@@ -669,6 +721,16 @@ struct CGDirArgs {
   int n_part_in;
   double tol;
   int maxit;
+  // peer transport: the halo entries of d go straight into the neighbours' vectors
+  PeerCG pc;
+  int n_nb;                         // neighbours that receive entries of my d
+  int nb_rank[kPeerRanks];
+  const int32_t *send_idx;          // owned rows to send, neighbour after neighbour
+  int send_off[kPeerRanks + 1];
+  double *peer_ghost[kPeerRanks];   // neighbour i: where my segment starts in ITS direction vector of ring slot 0
+  long long peer_stride[kPeerRanks];  // doubles between its ring slots
+  unsigned int *cnt;                // workgroups that have pushed (the last one publishes the tags)
+  int n_push_wg;                    // workgroups [0, n_push_wg) push halo entries besides their share of d
 };
 __global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
   __shared__ double red[4];
@@ -682,6 +744,7 @@ __global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
   double2 ov{0.0, 0.0}, gv{0.0, 0.0};
   if (i0 < n2) { ov = o2[i0]; gv = g2[i0]; }
   double beta = 0.0;
+  const int it = a.st->it_k2;
   if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
   for (int64_t i = i0; i < n2; i += stride) {
     if (i != i0) { ov = o2[i]; gv = g2[i]; }
@@ -693,6 +756,67 @@ __global__ __launch_bounds__(kThreads) void cg_direction_kernel(CGDirArgs a) {
     const int64_t i = a.n - 1;
     a.d[i] = beta * a.d_old[i] - a.g[i];
   }
+  if (a.pc.area && (int)blockIdx.x < a.n_push_wg) {
+    // the entries of d my neighbours need, formed again from d_old and g and stored into THEIR vectors
+    for (int i = 0; i < a.n_nb; ++i) {
+      double *dst = a.peer_ghost[i] + (long long)(it & 7) * a.peer_stride[i];
+      const int cnt = a.send_off[i + 1] - a.send_off[i];
+      for (int k = blockIdx.x * kThreads + threadIdx.x; k < cnt; k += a.n_push_wg * kThreads) {
+        const int li = a.send_idx[a.send_off[i] + k];
+        dst[k] = beta * a.d_old[li] - a.g[li];
+      }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(a.cnt, 1u) == (unsigned)a.n_push_wg - 1u) {
+      *a.cnt = 0;
+      for (int i = 0; i < a.n_nb; ++i)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.pc.peer_area[a.nb_rank[i]] + 2048 + (it & 7) * 64) + a.pc.me,
+                           a.pc.tag0 + (unsigned long long)it + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// One workgroup: this rank's sum of the partials (fixed order) -> every rank's slot (value, then the tag) -> wait for
+// everybody's tags -> out[0] = the total, added in rank order.  The consumer kernel reads out[] as a one-element
+// "partials" array.  kind 0: |g|^2 that opens iteration it (after the init kernel: it = 0; after an update: it =
+// iterations completed); kind 1: d.h of iteration it.
+struct PeerSumArgs {
+  PeerCG pc;
+  const double *part;
+  int n_part, kind, from_init;
+  const CGState *st;
+  double *out;
+};
+__global__ __launch_bounds__(kThreads) void peer_allsum_kernel(PeerSumArgs a) {
+  __shared__ double red[4];
+  if (!a.from_init && a.st->done) return;
+  if (*(volatile int *)a.pc.abort_flag) return;
+  const int it = a.kind == 0 ? (a.from_init ? 0 : a.st->it_k2) : a.st->it_k1;
+  const double s = reduce_partials(a.part, a.n_part, red);
+  const unsigned long long tag = a.pc.tag0 + (unsigned long long)it + (a.kind == 1 ? 1ull : 0ull);
+  const int off = (a.kind * 8 + (it & 7)) * 128;
+  if ((int)threadIdx.x < a.pc.n_ranks) reinterpret_cast<double *>(a.pc.peer_area[threadIdx.x] + off)[a.pc.me] = s;
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < a.pc.n_ranks)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.pc.peer_area[threadIdx.x] + off + 64) + a.pc.me, tag, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  if (!peer_cg_wait(a.pc, peer_cg_tags(a.pc, a.kind, it), (1u << a.pc.n_ranks) - 1u, tag)) return;
+  if (threadIdx.x == 0) {
+    const double *v = peer_cg_vals(a.pc, a.kind, it);
+    double tot = __builtin_nontemporal_load(v);
+    for (int r = 1; r < a.pc.n_ranks; ++r) tot += __builtin_nontemporal_load(v + r);
+    a.out[0] = tot;
+  }
+}
+
+// One workgroup, in front of the SpMV of iteration it: the neighbours' direction kernels have stored their entries of d
+__global__ __launch_bounds__(64) void peer_wait_halo_kernel(PeerCG pc, const CGState *st) {
+  if (st->done || *(volatile int *)pc.abort_flag) return;
+  const int it = st->it_k1;
+  const unsigned long long *tags = reinterpret_cast<const unsigned long long *>(pc.area + 2048 + (it & 7) * 64);
+  (void)peer_cg_wait(pc, tags, pc.nb_mask, pc.tag0 + (unsigned long long)it + 1ull);
 }
 
 // ---------------------------------------------------------------- coarse CG: init + update
@@ -796,8 +920,8 @@ __global__ __launch_bounds__(kThreads) void cg_update_g_kernel(CGUpdateGArgs a) 
   const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, stride = (int64_t)gridDim.x * kThreads;
   double2 hv{0.0, 0.0}, gv{0.0, 0.0};
   if (i0 < n2) { hv = h2[i0]; gv = g2[i0]; }
-  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
   const int it = a.st->it_k1;
+  const double dh = reduce_partials(a.part_dh, a.n_part_dh, red);
   const double alpha = a.st->gh[it & 1] / dh;
   double acc = 0.0;
   for (int64_t i = i0; i < n2; i += stride) {

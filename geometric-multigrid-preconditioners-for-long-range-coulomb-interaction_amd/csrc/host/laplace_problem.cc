@@ -1022,9 +1022,10 @@ int LaplaceProblem<dim>::upload() {
     // levels >= 1, transfers and copy indices are replicated.  A level 0 whose
     // coarse-CG iteration is shorter than the three collectives it would need stays replicated.
     const int64_t n0 = mg_matrices[0].n_rows;
-    // rows taken off every rank's coarse iteration (28 ps per row on one MI355X) against ~3 x 15 us of collectives
+    // rows taken off every rank's coarse iteration against what the exchange costs on the transport in use
+    const bool peer_transport = comm_id.compare(0, 8, "GMGPEER:") == 0;
     level0_partitioned = par.partition_level0 == "always" ||
-                         (par.partition_level0 != "never" && n0 - n0 / n_ranks >= kPartitionMinRowsSaved);
+                         (par.partition_level0 != "never" && n0 - n0 / n_ranks >= (peer_transport ? kPartitionMinRowsSavedPeer : kPartitionMinRowsSaved));
     GMGC(gmg_set_global_sizes(gmg, S.n_rows, level0_partitioned ? n0 : 0));
     const LocalOperator Sl = localize(S, rank, n_ranks);
     GMGC(gmg_set_system_matrix(gmg, Sl.A.n_rows, Sl.A.n_cols, Sl.A.rowptr.data(), Sl.A.col.data(), Sl.A.val.data()));
@@ -1061,6 +1062,7 @@ int LaplaceProblem<dim>::upload() {
   const int64_t chunk = (S.n_rows + n_ranks - 1) / n_ranks;
   GMGC(gmg_vec_alloc(gmg, chunk * n_ranks, &d_full));
   GMGC(gmg_vec_upload(gmg, d_rhs, system_rhs.data() + d_begin, d_n));
+  GMGC(gmg_comm_barrier(gmg));  // the ranks' assembly times differ by seconds; inside the solve they wait for each other in kernels
   return GMG_OK;
 }
 

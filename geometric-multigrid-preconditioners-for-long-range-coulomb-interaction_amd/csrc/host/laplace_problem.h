@@ -138,7 +138,10 @@ class LaplaceProblem {
   int rank = 0, n_ranks = 1;
   bool distributed = false;
   bool level0_partitioned = false;  // decided per cycle in upload() ("Partition level 0")
-  static constexpr int64_t kPartitionMinRowsSaved = 2500000;
+  // rows a rank must get rid of for a partitioned level 0 to pay (24 ps per row and coarse iteration on one MI355X):
+  // over RCCL an iteration gains three collectives + their launches (~60 us), over the peer transport three
+  // one-workgroup kernels and three flag latencies (~17 us)
+  static constexpr int64_t kPartitionMinRowsSaved = 2500000, kPartitionMinRowsSavedPeer = 700000;
   std::string comm_id;  // gmg_comm_unique_id of rank 0, broadcast by the launcher
   void set_communicator(int rank_, int n_ranks_, const std::string &id) { rank = rank_; n_ranks = n_ranks_; comm_id = id; distributed = true; }
 

@@ -148,6 +148,9 @@ int gmg_comm_unique_id(void *out_id);                       /* rank 0, then broa
                                                              * HBM, flags instead of collectives); it also works between
                                                              * processes sharing one GPU (tests)                              */
 int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
+/* The ranks meet on the host (call it when the operators are set, before the solve: the ranks' host-side setup times
+ * differ by seconds, the kernels of the peer transport wait for each other by polling).  No-op without a communicator. */
+int gmg_comm_barrier(gmg_context *ctx);
 /* Distributed layout: the system matrix / outer-CG vectors and level 0 (matrix,
  * coarse CG) are row-partitioned in equal chunks -- gmg_partition_range gives the canonical
  * owned range, mirroring locally_owned_dofs() of the reference (:656-657) -- while levels >= 1,
