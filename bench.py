@@ -91,6 +91,9 @@ def main():
                     help="N > 1: row-partition level 0 (coarse CG over RCCL) or keep it replicated; auto decides by size (DESIGN.md 6)")
     ap.add_argument("--refinement-estimator", default="Kelly", choices=["Kelly", "Kelly + residual"],
                     help="marking rule: Kelly = the cluster runs (January 2018), Kelly + residual = the reference's HEAD")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
+                    help="N > 1: RCCL collectives, or the peer-to-peer transport (hipIpc mailboxes, kernels store into the "
+                         "peer's HBM and poll flags: no collective launches; DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8)
     args = ap.parse_args()
@@ -140,7 +143,11 @@ def main():
                              refinement_estimator=args.refinement_estimator))
     p.set_nacl_atoms(w["nacl"])
     if launched:
-        # one process per GPU over RCCL: rank 0 creates the id, everybody joins (gmg_comm_init)
+        # one process per GPU: rank 0 creates the id (RCCL, or the name of the peer transport's start-up segment),
+        # everybody joins (gmg_comm_init)
+        if args.transport == "peer":
+            os.environ["GMG_COMM_TRANSPORT"] = "peer"
+            os.environ.setdefault("GMG_PEER_SLOT_MB", "64")
         box = [pkg.capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         p.set_communicator(rank, world, box[0])
@@ -287,7 +294,7 @@ def main():
                        "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
                        "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
                        "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),
-                       "rccl_ranks": world if launched else 0, "commit": git_head(),
+                       "rccl_ranks": world if (launched and args.transport == "rccl") else 0, "peer_ranks": world if (launched and args.transport == "peer") else 0, "commit": git_head(),
                        "parallelism": f"{world} rank(s), one per GPU" + ("" if world == 1 else (
                            "; system matrix + outer CG rows partitioned, level 0 " +
                            ("partitioned (halo exchange + 2 all-reduces per coarse iteration over RCCL)" if int(n0) < rep["dofs_by_level"][0]
