@@ -20,11 +20,12 @@ def main():
     part = sys.argv[7] if len(sys.argv) > 7 else "always"  # small problems: "auto" would keep level 0 replicated
     blocks = int(sys.argv[8]) if len(sys.argv) > 8 else 1   # SSOR blocks (0: one per rank, the reference on that many ranks)
     S = pkg().step50
-    if nacl:  # lattice of nacl^3 atoms, Jacobi smoother: the bench's kind of problem, three-kernel coarse CG on request
+    if nacl:  # the cluster runs' problem (BASELINE configs 2-5): NaCl lattice of 8 nacl^3 atoms, SSOR smoother, Kelly marking
         cycles = 2
         p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
-                                 bc="Homogeneous", cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1,
-                                 global_refinement=0, smoother="Jacobi", partition_level0=part))
+                                 bc="Inhomogeneous", cycles=cycles, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1,
+                                 global_refinement=0, smoother="SSOR", ssor_blocks=blocks, partition_level0=part,
+                                 refinement_estimator="Kelly"))
         p.set_nacl_atoms(nacl)
     else:
         cycles = 6
