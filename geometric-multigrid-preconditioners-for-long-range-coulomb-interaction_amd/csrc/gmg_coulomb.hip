@@ -554,9 +554,6 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
         }
         if (longest > 64) m.use_sellp = false;  // slice metadata lives in the 64 lanes
         else {
-          HIPC(hipMalloc(&m.sellp_wave_ptr, sizeof(int32_t) * wp.size()));
-          HIPC(hipMemcpyAsync(m.sellp_wave_ptr, wp.data(), sizeof(int32_t) * wp.size(), hipMemcpyHostToDevice, ctx->stream));
-          HIPC(hipStreamSynchronize(ctx->stream));
           // ---- row classes of the run-pattern slices (N4): the 27-tuple of value codes of a row; a lattice operator
           // has a few dozen of them.  Too many classes (> kSellpMaxClasses): the per-entry codes stay in use.
           if (!ctx->disable_rowclass) {
@@ -585,8 +582,17 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
               HIPC(hipStreamSynchronize(ctx->stream));
               m.rowclass = true;
               m.n_classes = (int)cls_of.size();
+              // waves whose slices are all run-pattern slices need no slice metadata (flag in their wave_ptr entry)
+              for (int wv = 0; wv < n_waves; ++wv) {
+                bool all = wp[(size_t)wv] < wp[(size_t)wv + 1];
+                for (int32_t s2 = wp[(size_t)wv]; s2 < wp[(size_t)wv + 1] && all; ++s2) all = spat[(size_t)s2] == m.sellp_pid;
+                if (all) wp[(size_t)wv] |= kSellpFastWave;
+              }
             }
           }
+          HIPC(hipMalloc(&m.sellp_wave_ptr, sizeof(int32_t) * wp.size()));
+          HIPC(hipMemcpyAsync(m.sellp_wave_ptr, wp.data(), sizeof(int32_t) * wp.size(), hipMemcpyHostToDevice, ctx->stream));
+          HIPC(hipStreamSynchronize(ctx->stream));
         }
       }
       if (!keep_csr) {  // the CSR copy is only kept where the SGS sweeps need it (levels >= 1)

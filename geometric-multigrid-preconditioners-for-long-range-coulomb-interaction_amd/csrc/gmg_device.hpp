@@ -528,10 +528,29 @@ struct SellPatArgs {
   int col16;       // layout of the column stream used by the other slices
 };
 
-// lane L <- value of lane L-1; lane 0 <- edge (wave-uniform)
+// lane L <- value of lane L-1; lane 0 <- its own lane of edge
 __device__ __forceinline__ double shift_in_from_left(double v, double edge) {
   const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// lane L <- value of lane L+1; lane 63 <- its own lane of edge
+__device__ __forceinline__ double shift_in_from_right(double v, double edge) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// lane L <- lane L+1 (lane 63 <- lane 0) / lane L <- lane L-1 (lane 0 <- lane 63)
+__device__ __forceinline__ double wave_rol1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_ror1(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13c /* wave_ror:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13c, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -539,15 +558,24 @@ __device__ __forceinline__ double lane_double(double v, int l) {  // l: wave-uni
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-constexpr int kSellpWaves = 6;  // resident waves per SIMD (= workgroups per CU) the register budget of the kernel is set for
+constexpr int kSellpWaves = 4;  // resident waves per SIMD (= workgroups per CU) the register budget of the kernel is set for
+constexpr int kSellpFastWave = 0x40000000;  // flag in wave_ptr[w]: every slice of wave w is a run-pattern slice with row classes
 
 // RC (row classes): on a lattice the rows of the run-pattern slices have few distinct coefficient
 // vectors (interior, next to a boundary face / edge / corner, Dirichlet rows).  Instead of one 8-bit code per ENTRY
 // (7 four-byte loads per slice and lane, a bit-field extract + a dictionary read per entry) the kernel reads one
-// class byte per ROW and takes the 27 coefficients from an LDS table at immediate offsets: 10 vector loads per slice
-// instead of 16, no per-entry address arithmetic, 47 MB less to stream at 121^3.  Same values in the same order.
+// class byte per ROW and takes the 27 coefficients from an LDS table at immediate offsets.  Same values, same order.
+//
+// What bounds the kernel at a lattice that fits the caches is the number of vector-memory instructions (a CU's
+// address unit takes ~16 cycles per instruction whatever its width) and of VALU instructions that move neighbours
+// between lanes.  With row classes two consecutive run-pattern slices are therefore processed as ONE unit of 128
+// rows, lane l <-> rows 2l and 2l + 1: per run one 16-byte load per lane brings both rows' middle columns, the left
+// column of the even row and the right column of the odd row come from the neighbouring lanes (one DPP shift each),
+// and y leaves as one 16-byte store: half the memory instructions and half the shifts per row.  A wave whose slices
+// are all run-pattern slices (flagged by the host) needs no slice metadata: the loads of its first unit go out right
+// after the scalar load of its slice range, before the tables are in LDS.
 template <int MODE, int CG, bool RC>
-__global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_sellp_kernel(SellPatArgs pa) {
+__global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_sellp_kernel(SellPatArgs pa) {
   constexpr bool XFORM = (CG == 1);  // fused opener: the operand is beta d_old - g, formed on the fly (small level 0)
   __shared__ double red[4];
   __shared__ double dict[256];
@@ -559,22 +587,85 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_se
   // that every XCD (own L2) walks one contiguous range of slices
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
   const int w = (xcd * nb + lb) * 4 + wid;
-  const int s0 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w]);
-  const int s1 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w + 1]);  // s1 - s0 <= 64 (host)
+  const int e0 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w]);
+  const int s0 = e0 & (kSellpFastWave - 1);
+  const int s1 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w + 1]) & (kSellpFastWave - 1);  // s1 - s0 <= 64 (host)
+  const bool fast = RC && (e0 & kSellpFastWave) != 0;
+  const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
+  const double *xb[9], *gb[9];
+  // lane u <-> the element left of run u's first row, lane 63 - u <-> the element right of its last row (the other
+  // lanes repeat lane 0: harmless, in range).  Run after run the register is rotated by one lane to the left (right),
+  // so that lane 0 (63) holds the edge the shift of that run takes in.
+  int my_edge = pa.centre[0] - 1;
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    xb[u] = a.x + pa.centre[u];
+    gb[u] = XFORM ? a.g + pa.centre[u] : nullptr;
+    if (lane == u) my_edge = pa.centre[u] - 1;
+    if (lane == 63 - u) my_edge = pa.centre[u];
+  }
+  const bool right_edge = lane >= 55;
+  double beta = 0.0;
+  // ---- a unit of 128 rows (two slices), lane <-> rows 2 lane, 2 lane + 1
+  struct XPair {
+    double2 p[9];
+    double edge;
+    int cls;  // two class bytes
+  };
+  auto issue_pair = [&](int s, XPair &R) {
+    const size_t row = (size_t)s * 64 + 2 * lane;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) R.p[u] = *reinterpret_cast<const double2 *>(xb[u] + row);  // 8-byte aligned 16-byte load
+    const size_t ec = (size_t)s * 64 + my_edge + (right_edge ? 128 : 0);
+    R.edge = a.x[ec];
+    if constexpr (RC) R.cls = *reinterpret_cast<const unsigned short *>(pa.rowcls + row);
+    if constexpr (XFORM) {
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const double2 gv = *reinterpret_cast<const double2 *>(gb[u] + row);
+        R.p[u].x = beta * R.p[u].x - gv.x;
+        R.p[u].y = beta * R.p[u].y - gv.y;
+      }
+      R.edge = beta * R.edge - a.g[ec];
+    }
+  };
+  // ---- a single run-pattern slice, lane <-> row
+  struct XRun {
+    double m[9];
+    double edge;
+    int cls;
+  };
+  auto issue = [&](int s, XRun &R) {
+    const size_t row = (size_t)s * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) R.m[u] = xb[u][row];
+    const size_t ec = (size_t)s * 64 + my_edge + (right_edge ? 64 : 0);
+    R.edge = a.x[ec];
+    if constexpr (RC) R.cls = pa.rowcls[row];
+    if constexpr (XFORM) {
+#pragma unroll
+      for (int u = 0; u < 9; ++u) R.m[u] = beta * R.m[u] - gb[u][row];
+      R.edge = beta * R.edge - a.g[ec];
+    }
+  };
+  XPair A;
+  bool a_ready = false;
   // slice metadata of the whole wave in one round trip, together with the dictionary: lane i <-> slice s0 + i
   int m_qb = 0, m_qe = 0, m_pid = -1;
-  if (s0 + lane < s1) {
+  if (fast) {
+    m_pid = pa.pid0;
+    if (!XFORM && s0 + 1 < s1) { issue_pair(s0, A); a_ready = true; }
+  } else if (s0 + lane < s1) {
     m_qb = sa.qptr[s0 + lane];
     m_qe = sa.qptr[s0 + lane + 1];
     m_pid = sa.spat[s0 + lane];
   }
   const double dict_mine = sa.dict[threadIdx.x];
-  double beta = 0.0;
   if constexpr (CG == 1) {
     if (!cg_open_iteration(a.st, a.part_in, a.n_part_in, a.tol, a.maxit, red, &beta)) return;
   }
   if constexpr (CG == 2) {
-    if (a.st->done) return;  // read after the loads above were issued: one round trip for all three
+    if (a.st->done) return;  // read after the loads above were issued: one round trip for all of them
   }
   dict[threadIdx.x] = dict_mine;
   if constexpr (RC) {
@@ -586,80 +677,144 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_se
     else return a.x[c];
   };
   double dot_acc = 0.0;
-  const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
-  const double *xb[9], *gb[9];
-  int my_centre = pa.centre[0];  // lanes 0..8 <-> runs (lanes >= 9 repeat run 0: harmless, in range)
-#pragma unroll
-  for (int u = 0; u < 9; ++u) {
-    xb[u] = a.x + pa.centre[u];
-    gb[u] = XFORM ? a.g + pa.centre[u] : nullptr;
-    if (lane == u) my_centre = pa.centre[u];
-  }
+  // what happens to a finished row sum
+  auto finish = [&](int r, double acc, double self, bool have_self) {
+    if constexpr (CG != 0) {
+      if (!have_self) self = X((size_t)r);
+      if constexpr (XFORM) a.dnew[r] = self;
+      a.y[r] = acc; dot_acc += self * acc;
+    } else if constexpr (MODE == kStore) a.y[r] = acc;
+    else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;
+    else if constexpr (MODE == kAddTo) a.y[r] = a.b[r] + acc;
+    else if constexpr (MODE == kJacobi) a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
+    else if constexpr (MODE == kCheb) {
+      const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
+      a.w[r] = wn; a.y[r] = a.x[r] + wn;
+    }
+  };
+  auto ld2 = [&](const double *q, size_t r) -> double2 { return *reinterpret_cast<const double2 *>(q + r); };
+  auto st2 = [&](double *q, size_t r, double v0, double v1) { *reinterpret_cast<double2 *>(q + r) = double2{v0, v1}; };
 
-  double carry[9];  // wave-uniform
-  bool have_carry = false;
-  for (int s = s0; s < s1; ++s) {
+  // ---- two run-pattern slices as one unit (all 128 rows exist)
+  auto sum_pair = [&](const int s, const XPair &A) {
+    {
+      const size_t row = (size_t)s * 64 + 2 * lane;  // even: 16-byte aligned vectors
+      double acc0 = 0.0, acc1 = 0.0;
+      if (a.init) { const double2 iv = ld2(a.init, row); acc0 = iv.x; acc1 = iv.y; }
+      // The coefficients of run u + 1 are read from the LDS table while run u is summed, and no earlier: 54 of them
+      // do not fit the registers, and left alone the compiler reads all of them first and spills.  Their LDS addresses
+      // are therefore made to "depend" on the sums as they stand when run u starts (an empty asm).
+      typedef const __attribute__((address_space(3))) double lds_cdouble;
+      const uint32_t tab = (uint32_t)(uintptr_t)(lds_cdouble *)ctab;
+      uint32_t b0 = tab + (uint32_t)(A.cls & 0xff) * 216u, b1 = tab + (uint32_t)((A.cls >> 8) & 0xff) * 216u;
+      auto coef = [](uint32_t base, int j) -> double { return *reinterpret_cast<lds_cdouble *>((uintptr_t)(base + 8u * (uint32_t)j)); };
+      double c0[3] = {coef(b0, 0), coef(b0, 1), coef(b0, 2)}, c1[3] = {coef(b1, 0), coef(b1, 1), coef(b1, 2)};
+      double el = A.edge, er = A.edge;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        double n0[3] = {0.0, 0.0, 0.0}, n1[3] = {0.0, 0.0, 0.0};
+        if (u < 8) {
+          asm volatile("" : "+v"(b0), "+v"(b1) : "v"(acc0), "v"(acc1));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { n0[j] = coef(b0, 3 * u + 3 + j); n1[j] = coef(b1, 3 * u + 3 + j); }
+        }
+        const double left = shift_in_from_left(A.p[u].y, el);
+        const double right = shift_in_from_right(A.p[u].x, er);
+        if (u < 8) { el = wave_rol1(el); er = wave_ror1(er); }
+        acc0 += c0[0] * left;
+        acc0 += c0[1] * A.p[u].x;
+        acc0 += c0[2] * A.p[u].y;
+        acc1 += c1[0] * A.p[u].x;
+        acc1 += c1[1] * A.p[u].y;
+        acc1 += c1[2] * right;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { c0[j] = n0[j]; c1[j] = n1[j]; }
+      }
+      if constexpr (CG != 0) {
+        double2 self;
+        if (pa.centre[4] == 0) self = A.p[4];
+        else { self.x = X(row); self.y = X(row + 1); }
+        if constexpr (XFORM) st2(a.dnew, row, self.x, self.y);
+        st2(a.y, row, acc0, acc1);
+        dot_acc += self.x * acc0;
+        dot_acc += self.y * acc1;
+      } else if constexpr (MODE == kStore) st2(a.y, row, acc0, acc1);
+      else if constexpr (MODE == kResid) { const double2 bv = ld2(a.b, row); st2(a.y, row, bv.x - acc0, bv.y - acc1); }
+      else if constexpr (MODE == kAddTo) { const double2 bv = ld2(a.b, row); st2(a.y, row, bv.x + acc0, bv.y + acc1); }
+      else if constexpr (MODE == kJacobi) {
+        const double2 bv = ld2(a.b, row), xv = ld2(a.x, row), dv = ld2(a.invd, row);
+        st2(a.y, row, xv.x + (a.omega * (bv.x - acc0)) * dv.x, xv.y + (a.omega * (bv.y - acc1)) * dv.y);
+      } else if constexpr (MODE == kCheb) {
+        const double2 bv = ld2(a.b, row), xv = ld2(a.x, row), dv = ld2(a.invd, row), wv = ld2(a.w, row);
+        const double wn0 = a.c1 * wv.x + a.omega * ((bv.x - acc0) * dv.x), wn1 = a.c1 * wv.y + a.omega * ((bv.y - acc1) * dv.y);
+        st2(a.w, row, wn0, wn1);
+        st2(a.y, row, xv.x + wn0, xv.y + wn1);
+      }
+    }
+  };
+  int s_begin = s0;
+  if (fast) {
+    // nothing but pairs (and at most one slice after them): the first pair's loads are already in flight
+    XPair P = A;
+    for (; s_begin + 1 < s1; s_begin += 2) {
+      if (!a_ready) issue_pair(s_begin, P);
+      a_ready = false;
+      sum_pair(s_begin, P);
+    }
+  }
+  for (int s = s_begin; s < s1;) {
     const int i = s - s0;
     const int pid = __builtin_amdgcn_readlane(m_pid, i);
+    if (RC && pid == pa.pid0 && s + 1 < s1 && __builtin_amdgcn_readlane(m_pid, i + 1) == pa.pid0) {
+      XPair P;
+      issue_pair(s, P);
+      sum_pair(s, P);
+      s += 2;
+      continue;
+    }
     const int qb = __builtin_amdgcn_readlane(m_qb, i);
     const int row = s * 64 + lane;
     const bool valid = row < sa.n_rows;
     double acc = (a.init && valid) ? a.init[row] : 0.0;
-    double self = 0.0;      // x[row] for the CG dot product: the centre of the middle run when that is the diagonal
+    double self = 0.0;      // x[row] for the CG dot product: the middle run when that is the diagonal
     bool have_self = false;
     if (pid == pa.pid0) {
-      // ---- nine runs of three: all 64 rows exist; 7 quads of codes per lane
-      double2 p[9];
+      // ---- one run-pattern slice: nine runs of three, all 64 rows exist; 7 quads of codes per lane
+      XRun C;
       uchar4 k[7];
-      const double *cw = ctab;  // RC: the row's 27 coefficients
-      if constexpr (RC) cw = ctab + (int)pa.rowcls[row] * 27;
-#pragma unroll
-      for (int u = 0; u < 9; ++u) p[u] = *reinterpret_cast<const double2 *>(xb[u] + row);  // 8-byte aligned 16-byte load
-      if constexpr (XFORM) {
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const double2 gv = *reinterpret_cast<const double2 *>(gb[u] + row);
-          p[u].x = beta * p[u].x - gv.x;
-          p[u].y = beta * p[u].y - gv.y;
-        }
-      }
+      issue(s, C);
       if constexpr (!RC) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) k[u] = kbase[(size_t)(qb + u) * 64];
       }
-      if (!have_carry) {  // first slice of the wave (or after a streamed slice): lane u fetches the element left of run u
-        const double e = X((size_t)s * 64 - 1 + my_centre);
-#pragma unroll
-        for (int u = 0; u < 9; ++u) carry[u] = lane_double(e, u);
-      }
+      const double *cw = ctab;  // RC: the row's 27 coefficients
+      if constexpr (RC) cw = ctab + C.cls * 27;
       // dictionary values of run u+1 are looked up before the products of run u are summed
       auto code_at = [&](int j) -> int {
-        const uchar4 w = k[j >> 2];
+        const uchar4 w4 = k[j >> 2];
         const int e = j & 3;
-        return e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w;
+        return e == 0 ? w4.x : e == 1 ? w4.y : e == 2 ? w4.z : w4.w;
       };
       auto coef = [&](int j) -> double {
         if constexpr (RC) return cw[j];
         else return dict[code_at(j)];
       };
       double w0 = coef(0), w1 = coef(1), w2 = coef(2);
+      double el = C.edge, er = C.edge;
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
         double n0 = 0.0, n1 = 0.0, n2 = 0.0;
         if (u < 8) { n0 = coef(3 * u + 3); n1 = coef(3 * u + 4); n2 = coef(3 * u + 5); }
-        const double left = shift_in_from_left(p[u].x, carry[u]);
+        const double left = shift_in_from_left(C.m[u], el);
+        const double right = shift_in_from_right(C.m[u], er);
+        if (u < 8) { el = wave_rol1(el); er = wave_ror1(er); }
         acc += w0 * left;
-        acc += w1 * p[u].x;
-        acc += w2 * p[u].y;
+        acc += w1 * C.m[u];
+        acc += w2 * right;
         w0 = n0; w1 = n1; w2 = n2;
       }
-      if (pa.centre[4] == 0) { self = p[4].x; have_self = true; }
-      // lane 63 of this slice is the left neighbour of lane 0 of the next one
-#pragma unroll
-      for (int u = 0; u < 9; ++u) carry[u] = lane_double(p[u].x, 63);
-      have_carry = true;
+      if (pa.centre[4] == 0) { self = C.m[4]; have_self = true; }
     } else {
-      have_carry = false;
       // ---- any other slice: quad by quad, the columns and codes of the next quad in flight while
       // the gathers of this one are summed
       const int qe = __builtin_amdgcn_readlane(m_qe, i);
@@ -670,11 +825,11 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_se
           const int j = (q - qb) * 4;
           c[0] = row + pat[j]; c[1] = row + pat[j + 1]; c[2] = row + pat[j + 2]; c[3] = row + pat[j + 3];
         } else if (pa.col16) {
-          const ushort4 C = (reinterpret_cast<const ushort4 *>(sa.cols) + lane)[(size_t)q * 64];
-          c[0] = base + C.x; c[1] = base + C.y; c[2] = base + C.z; c[3] = base + C.w;
+          const ushort4 Cq = (reinterpret_cast<const ushort4 *>(sa.cols) + lane)[(size_t)q * 64];
+          c[0] = base + Cq.x; c[1] = base + Cq.y; c[2] = base + Cq.z; c[3] = base + Cq.w;
         } else {
-          const int4 C = (reinterpret_cast<const int4 *>(sa.cols) + lane)[(size_t)q * 64];
-          c[0] = C.x; c[1] = C.y; c[2] = C.z; c[3] = C.w;
+          const int4 Cq = (reinterpret_cast<const int4 *>(sa.cols) + lane)[(size_t)q * 64];
+          c[0] = Cq.x; c[1] = Cq.y; c[2] = Cq.z; c[3] = Cq.w;
         }
       };
       int c[4] = {0, 0, 0, 0};
@@ -687,21 +842,8 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 4 : kSellpWaves)) void spmv_se
         acc += dict[k0.x] * v0; acc += dict[k0.y] * v1; acc += dict[k0.z] * v2; acc += dict[k0.w] * v3;
       }
     }
-    if (valid) {
-      const int r = row;
-      if constexpr (CG != 0) {
-        if (!have_self) self = X((size_t)r);
-        if constexpr (XFORM) a.dnew[r] = self;
-        a.y[r] = acc; dot_acc += self * acc;
-      } else if constexpr (MODE == kStore) a.y[r] = acc;
-      else if constexpr (MODE == kResid) a.y[r] = a.b[r] - acc;
-      else if constexpr (MODE == kAddTo) a.y[r] = a.b[r] + acc;
-      else if constexpr (MODE == kJacobi) a.y[r] = a.x[r] + (a.omega * (a.b[r] - acc)) * a.invd[r];
-      else if constexpr (MODE == kCheb) {
-        const double wn = a.c1 * a.w[r] + a.omega * ((a.b[r] - acc) * a.invd[r]);
-        a.w[r] = wn; a.y[r] = a.x[r] + wn;
-      }
-    }
+    if (valid) finish(row, acc, self, have_self);
+    ++s;
   }
   if constexpr (CG != 0) {
     const double sblock = block_sum(dot_acc, red);
