@@ -544,13 +544,13 @@ __device__ __forceinline__ double shift_in_from_right(double v, double edge) {
 
 // lane L <- lane L+1 (lane 63 <- lane 0) / lane L <- lane L-1 (lane 0 <- lane 63)
 __device__ __forceinline__ double wave_rol1(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134 /* wave_rol:1 */, 0xf, 0xf, false);  // (every lane is written)
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_ror1(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13c /* wave_ror:1 */, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13c, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x13c /* wave_ror:1 */, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x13c, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -614,8 +614,11 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_se
   };
   auto issue_pair = [&](int s, XPair &R) {
     const size_t row = (size_t)s * 64 + 2 * lane;
+    // uniform base + 32-bit byte offset of the lane: one address register for the nine loads (n_rows < 2^28)
+    const uint32_t off = ((uint32_t)s * 64u + 2u * (uint32_t)lane) * 8u;
 #pragma unroll
-    for (int u = 0; u < 9; ++u) R.p[u] = *reinterpret_cast<const double2 *>(xb[u] + row);  // 8-byte aligned 16-byte load
+    for (int u = 0; u < 9; ++u)
+      R.p[u] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(xb[u]) + off);  // 8-byte aligned 16-byte load
     const size_t ec = (size_t)s * 64 + my_edge + (right_edge ? 128 : 0);
     R.edge = a.x[ec];
     if constexpr (RC) R.cls = *reinterpret_cast<const unsigned short *>(pa.rowcls + row);
@@ -710,11 +713,13 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_se
       auto coef = [](uint32_t base, int j) -> double { return *reinterpret_cast<lds_cdouble *>((uintptr_t)(base + 8u * (uint32_t)j)); };
       double c0[3] = {coef(b0, 0), coef(b0, 1), coef(b0, 2)}, c1[3] = {coef(b1, 0), coef(b1, 1), coef(b1, 2)};
       double el = A.edge, er = A.edge;
+      double t0 = acc0, t1 = acc1;  // the sums one run back
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
         double n0[3] = {0.0, 0.0, 0.0}, n1[3] = {0.0, 0.0, 0.0};
         if (u < 8) {
-          asm volatile("" : "+v"(b0), "+v"(b1) : "v"(acc0), "v"(acc1));
+          asm volatile("" : "+v"(b0), "+v"(b1) : "v"(t0), "v"(t1));
+          t0 = acc0; t1 = acc1;
 #pragma unroll
           for (int j = 0; j < 3; ++j) { n0[j] = coef(b0, 3 * u + 3 + j); n1[j] = coef(b1, 3 * u + 3 + j); }
         }

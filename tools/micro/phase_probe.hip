@@ -155,5 +155,11 @@ int main() {
   run<3, 0, 16, 0>(src, out);
   run<4, 0, 16, 0>(src, out);
   run<3, 2, 8, 0>(src, out);
+  run<1, 0, 16, 0>(src, out);
+  run<2, 0, 16, 0>(src, out);
+  run<1, 0, 24, 0>(src, out);
+  run<2, 0, 24, 0>(src, out);
+  run<3, 0, 24, 0>(src, out);
+  run<2, 1, 16, 0>(src, out);
   return 0;
 }
