@@ -9,6 +9,7 @@
 #include "../../include/gmg_coulomb.h"
 #include "gmg_device.hpp"
 #include "gmg_sgs.hpp"
+#include "gmg_sgs_phase.hpp"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -76,6 +77,9 @@ struct SgsPlan {
   std::vector<int32_t> host_block_row;  // n_blocks + 1 (several ranks: who sweeps which rows)
   double *w_stage = nullptr;            // staging of the all-gather of the swept pieces
   int64_t w_stage_len = 0;
+  // three-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
+  bool phased = false;
+  PhRange *p_ranges = nullptr;
 };
 
 struct Level {
@@ -135,7 +139,7 @@ struct gmg_context {
   int coarse_chunk = 0;
   // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
-  bool sgs_disable_wave = false, debug_upload = false, sgs_profile = false;
+  bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
@@ -788,7 +792,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
     const int nbl = split ? L.sgs.n_blocks / n_ranks : L.sgs.n_blocks;
     p.block0 = split ? ctx->comm.rank * nbl : 0;
     if (L.sgs.w_n_coupled > 0) {
-      if (ctx->sgs_profile) return sgs_profile_launch(ctx, L, p);
+      if (ctx->sgs_profile && !L.sgs.phased) return sgs_profile_launch(ctx, L, p);
       if (ctx->prof_every > 0 && !ctx->ev_e.empty()) {
         if (ctx->ev3_used == (int)ctx->ev_e.size()) collect_sgs_samples(ctx);  // pool full: drain it (synchronises; profiling runs only)
         ctx->timed_start = ctx->ev_e[(size_t)ctx->ev3_used]; ctx->timed_stop = ctx->ev_f[(size_t)ctx->ev3_used++];
@@ -796,7 +800,14 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
         ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
       }
       const size_t lds = ctx->sgs_lds_bytes_override > 0 ? (size_t)ctx->sgs_lds_bytes_override : (size_t)L.sgs.w_lds_bytes;
-      launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
+      if (L.sgs.phased) {
+        SgsPhaseArgs q{};
+        q.ranges = L.sgs.p_ranges; q.block_rng = p.block_rng; q.block0 = p.block0; q.stream = p.stream; q.ws_ci = p.ws_ci; q.ci_row = p.ci_row;
+        q.ycur = p.ycur; q.y = p.y; q.omega = p.omega; q.y_slots = p.y_slots; q.prof = nullptr;
+        launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
+      } else {
+        launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
+      }
     }
     if (split) {
       const std::vector<int32_t> &br = L.sgs.host_block_row;
@@ -1143,7 +1154,7 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
 void free_sgs(SgsPlan &g) {
   for (void *p : {(void *)g.stage_ptr, (void *)g.stage_rows, (void *)g.block_row, (void *)g.block_stage, (void *)g.w_ranges,
                   (void *)g.w_block_rng, (void *)g.w_ws_ci, (void *)g.w_ci_row, (void *)g.w_row_ci, (void *)g.w_rpos_f, (void *)g.w_rpos_b,
-                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd, (void *)g.w_stage})
+                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd, (void *)g.w_stage, (void *)g.p_ranges})
     if (p) (void)hipFree(p);
   g = SgsPlan();
 }
@@ -1151,12 +1162,19 @@ void free_sgs(SgsPlan &g) {
 // Plan of the wavefront sweep (gmg_sgs.hpp): per block the pruned rows, the dependency stages, the steps of both
 // sweep directions, their grouping into LDS-sized ranges, and the record stream in consumption order.
 int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, const int32_t *col, const double *val, int n_blocks,
-                   const std::vector<int32_t> &block_row) {
+                   const std::vector<int32_t> &block_row, bool allow_phase = true) {
   SgsPlan &G = L.sgs;
   G.wave = false;
   if (n <= 0 || ctx->sgs_disable_wave) return GMG_OK;
-  int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : kSwYSlots;
-  y_cap = std::max(64, std::min(y_cap, kSwYSlots)) & ~1;
+  // three waves in turn (gmg_sgs_phase.hpp) unless switched off; rows wider than its records hold fall back to one wave
+  bool ph = allow_phase && !ctx->sgs_disable_phase && !ctx->sgs_profile;
+  if (ph) {
+    for (int64_t i = 0; i < n && ph; ++i) ph = rp[i + 1] - rp[i] <= 2 * kPhMaxEntries;  // (cheap pre-check; the exact one is per range)
+  }
+  const int y_max = ph ? kPhYSlots : kSwYSlots;
+  int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : y_max;
+  y_cap = std::max(64, std::min(y_cap, y_max)) & ~1;
+  std::vector<PhRange> pranges;
   std::vector<int32_t> row_ci((size_t)n, -1), ci_row, rpos_f, rpos_b, ws_ci, block_rng((size_t)n_blocks + 1, 0);
   std::vector<double> iso_diag((size_t)n, 0.0), iso_invd((size_t)n, 1.0);
   std::vector<SwRange> ranges;
@@ -1166,7 +1184,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   for (int b = 0; b < n_blocks; ++b) {
     const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
     const int m = (int)(re - rb);
-    block_rng[(size_t)b] = (int32_t)ranges.size();
+    block_rng[(size_t)b] = (int32_t)(ph ? pranges.size() : ranges.size());
     if (m == 0) continue;
     // ---- in-block nonzero entries of every row (local column numbers), 1 / a_ii as in setup_diag
     std::vector<int32_t> prp((size_t)m + 1, 0), pcol;
@@ -1225,6 +1243,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     std::vector<int32_t> ws_stamp((size_t)m, -1), own_stamp((size_t)m, -1), tmp_stamp((size_t)m, -1), slot_of((size_t)m, 0);
     std::vector<int32_t> prefix_pos((size_t)m, 0);  // index (doubles) of the row's prefix field in the backward records
     std::vector<SwRange> dir_ranges[2];
+    std::vector<PhRange> dir_pranges[2];
+    std::vector<int32_t> step_of((size_t)m, -1);
+    std::vector<int32_t> upd_stamp((size_t)m, -1);  // == stamp_id: the row is updated in the current range
     int stamp_id = 0, tmp_id = 0;
     for (int dir = 1; dir >= 0; --dir) {  // backward first: the forward records point into the backward ones
       // entries of a row in this direction: forward = the columns j < i (y_j = 0 for j >= i); backward = the columns
@@ -1249,7 +1270,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         }
         if (ctx->sgs_groups > 0) g_dir = std::min(4, ctx->sgs_groups);
       }
-      const int w_dir = 8 * g_dir, stride = sw_stride(g_dir);
+      const int w_dir = 8 * g_dir, stride = ph ? ph_stride(3, 12) : sw_stride(g_dir);
+      const int max_rows = ph ? kPhMaxRows : 64;
       // ---- steps: <= 64 rows of one stage, records of a sub-step <= kSwMaxBlock bytes, working set <= y_cap
       struct Step { int32_t first, nrows, len; };
       std::vector<int32_t> seq;
@@ -1263,7 +1285,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           const int li = n_ent(i);
           const int nl = std::max(cur.len, li);
           const int64_t raw = 16 + (int64_t)(cur.nrows + 1) * stride;
-          if (cur.nrows > 0 && (cur.nrows == 64 || raw > kSwMaxBlock || (cur.nrows + 1) * (nl + 1) > y_cap)) {
+          if (cur.nrows > 0 && (cur.nrows == max_rows || (!ph && raw > kSwMaxBlock) || (cur.nrows + 1) * (nl + 1) > y_cap)) {
             steps.push_back(cur);
             cur = Step{(int32_t)seq.size(), 0, 0};
           }
@@ -1331,6 +1353,106 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         R.backward = dir;
         R.groups = g_dir;
         R.n_steps = 0;
+        if (ph) {
+          // ---- three-wave records.  step_of: the step (of this range) that updates a row; a row's TAIL starts at its first
+          // column updated by the step right before its own
+          for (size_t st = s0; st < s1; ++st)
+            for (int u = 0; u < steps[st].nrows; ++u) {
+              step_of[(size_t)seq[(size_t)(steps[st].first + u)]] = (int32_t)(st - s0);
+              upd_stamp[(size_t)seq[(size_t)(steps[st].first + u)]] = stamp_id;
+            }
+          int max_tail = 0, max_n = 0;
+          std::vector<int32_t> tail_of;  // per row of the range, in step order
+          for (size_t st = s0; st < s1; ++st)
+            for (int u = 0; u < steps[st].nrows; ++u) {
+              const int i = seq[(size_t)(steps[st].first + u)];
+              int ne = 0, first_late = -1;
+              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
+                const int c = pcol[(size_t)k];
+                if (!in_dir(i, c)) continue;
+                if (first_late < 0 && c != i && upd_stamp[(size_t)c] == stamp_id && step_of[(size_t)c] == (int32_t)(st - s0) - 1) first_late = ne;
+                ++ne;
+              }
+              const int tl = first_late < 0 ? 0 : ne - first_late;
+              tail_of.push_back(tl);
+              max_tail = std::max(max_tail, tl); max_n = std::max(max_n, ne);
+            }
+          const int Lr = std::max(4, (max_tail + 3) / 4 * 4);
+          const int Gr = (std::max(0, max_n - Lr) + 7) / 8;
+          if (!ph_shape_ok(Gr, Lr)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+          const int pstride = ph_stride(Gr, Lr);
+          PhRange P{};
+          P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir; P.G = Gr; P.L = Lr;
+          P.n_steps = (int32_t)(s1 - s0);
+          const int64_t base = ((int64_t)stream.size() + 1023) / 1024 * 1024;
+          P.stream_off = base;
+          std::vector<int64_t> boff, bbytes;
+          int64_t off = 0;
+          size_t tix = 0;
+          for (size_t st = s0; st < s1; ++st) {
+            const Step &S = steps[st];
+            const int64_t raw = 16 + (int64_t)S.nrows * pstride;
+            boff.push_back(off); bbytes.push_back(raw);
+            stream.resize((size_t)(base + off + raw), 0);
+            char *blk = stream.data() + base + off;
+            reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)S.nrows;
+            for (int u = 0; u < S.nrows; ++u) {
+              const int i = seq[(size_t)(S.first + u)];
+              const int32_t ci = row_ci[(size_t)(rb + i)];
+              char *rec = blk + 16 + (size_t)u * pstride;
+              const int64_t rec_pos = base + off + 16 + (int64_t)u * pstride;
+              (dir == 0 ? rpos_f : rpos_b)[(size_t)ci] = (int32_t)(rec_pos / 8);
+              if (dir == 1) prefix_pos[(size_t)i] = (int32_t)(rec_pos / 8 + 2);
+              double *f = reinterpret_cast<double *>(rec);
+              uint32_t *wv = reinterpret_cast<uint32_t *>(rec);
+              const uint32_t my = (uint32_t)slot_of[(size_t)i] * 8u;
+              f[0] = 0.0; f[1] = invd[(size_t)i]; f[2] = 0.0;
+              wv[6] = my;
+              wv[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
+              double *hv = f + 4, *tv = f + 4 + 8 * Gr;
+              uint32_t *ha = reinterpret_cast<uint32_t *>(rec + 32 + 64 * Gr + 8 * Lr), *ta = ha + 8 * Gr;
+              for (int e = 0; e < 8 * Gr; ++e) { hv[e] = 0.0; ha[e] = my; }
+              for (int e = 0; e < Lr; ++e) { tv[e] = 0.0; ta[e] = my; }
+              // the tail: the last max(required, n - 8 G) entries -- never fewer than the columns from the first late one on
+              int ne = 0;
+              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) ne += in_dir(i, pcol[(size_t)k]);
+              const int tcount = std::max((int)tail_of[tix], std::max(0, ne - 8 * Gr));
+              const int hcount = ne - tcount;
+              int e = 0;
+              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
+                const int c = pcol[(size_t)k];
+                if (!in_dir(i, c)) continue;
+                if (e < hcount) { hv[e] = pval[(size_t)k]; ha[e] = (uint32_t)slot_of[(size_t)c] * 8u; }
+                else { tv[e - hcount] = pval[(size_t)k]; ta[e - hcount] = (uint32_t)slot_of[(size_t)c] * 8u; }
+                ++e;
+              }
+              ++tix;
+            }
+            off += (raw + 15) / 16 * 16;
+          }
+          for (size_t q = 0; q < boff.size(); ++q) {
+            uint32_t *h = reinterpret_cast<uint32_t *>(stream.data() + base + boff[q]);
+            if (q + 3 < boff.size()) { h[1] = (uint32_t)bbytes[q + 3]; h[2] = (uint32_t)boff[q + 3]; }
+            if (q < 3) { P.blk_off[q] = (uint32_t)boff[q]; P.blk_bytes[q] = (uint32_t)bbytes[q]; }
+          }
+          const int64_t padded = (off + 2048 + 1023) / 1024 * 1024;  // the copies read whole KB: up to 1008 bytes beyond a block
+          if (padded >= ((int64_t)1 << 31) || (base + padded) / 8 >= ((int64_t)1 << 31)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+          stream.resize((size_t)(base + padded), 0);
+          P.stream_bytes = (uint32_t)padded;
+          // prefetch wave: pf_step bytes per phase starting pf_lead bytes ahead, never behind block p + 12 at phase p
+          const int64_t nph = P.n_steps + 2;
+          const int64_t step_b = ((off + nph - 1) / nph + 127) / 128 * 128;
+          int64_t lead = 65536;
+          for (int64_t q = 0; q < (int64_t)boff.size(); ++q) {
+            const int64_t need = boff[(size_t)std::min<int64_t>(q + 12, (int64_t)boff.size() - 1)] + kPhRegion;  // by phase q - 2
+            lead = std::max(lead, need - std::max<int64_t>(q - 2, 0) * step_b);
+          }
+          P.pf_step = (uint32_t)step_b; P.pf_lead = (uint32_t)((lead + 8191) / 8192 * 8192);
+          total_steps += P.n_steps;
+          dir_pranges[dir].push_back(P);
+          s0 = s1;
+          continue;
+        }
         // ---- records in consumption order; a block never straddles the end of the ring
         const int64_t base = ((int64_t)stream.size() + kSwChunk - 1) / kSwChunk * kSwChunk;
         R.stream_off = base;
@@ -1402,13 +1524,15 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
       }
     }
     for (int dir = 0; dir < 2; ++dir) ranges.insert(ranges.end(), dir_ranges[dir].begin(), dir_ranges[dir].end());
+    for (int dir = 0; dir < 2; ++dir) pranges.insert(pranges.end(), dir_pranges[dir].begin(), dir_pranges[dir].end());
   }
-  block_rng[(size_t)n_blocks] = (int32_t)ranges.size();
+  block_rng[(size_t)n_blocks] = (int32_t)(ph ? pranges.size() : ranges.size());
   const int y_slots = std::max(2, (max_ws + 1) & ~1);
 #define SW_UP(dst, vec, T)                                                                                          \
   HIPC(hipMalloc(&dst, sizeof(T) * std::max<size_t>((vec).size(), 1)));                                              \
   if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
   SW_UP(G.w_ranges, ranges, SwRange)
+  SW_UP(G.p_ranges, pranges, PhRange)
   SW_UP(G.w_block_rng, block_rng, int32_t)
   SW_UP(G.w_ws_ci, ws_ci, int32_t)
   SW_UP(G.w_ci_row, ci_row, int32_t)
@@ -1433,20 +1557,22 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     }
   }
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = y_slots * 8 + kSwRing + 32;
-  G.w_n_ranges = (int)ranges.size();
+  G.w_lds_bytes = ph ? y_slots * 8 + 3 * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
+  G.w_n_ranges = (int)(ph ? pranges.size() : ranges.size());
+  G.phased = ph;
   G.w_n_coupled = (int64_t)ci_row.size();
   G.w_stream_bytes = (int64_t)stream.size();
   G.w_steps = total_steps; G.w_stages = total_stages;
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPC(hipFuncSetAttribute((const void *)sgs_phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // the sweep bakes absolute LDS addresses into its records: its dynamic LDS must start at 0 (no static __shared__)
   hipFuncAttributes fa{};
-  HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_wave_kernel<false>));
+  HIPC(hipFuncGetAttributes(&fa, ph ? (const void *)sgs_phase_kernel : (const void *)sgs_wave_kernel<false>));
   G.wave = fa.sharedSizeBytes == 0;
   if (ctx->debug_upload)
-    std::fprintf(stderr, "[gmg] SGS wave plan: %lld rows, %lld coupled, %d blocks, %lld stages, %lld sub-steps, %d ranges, y slots %d, stream %.1f MB\n",
-                 (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
+    std::fprintf(stderr, "[gmg] SGS %s plan: %lld rows, %lld coupled, %d blocks, %lld stages, %lld sub-steps, %d ranges, y slots %d, stream %.1f MB\n",
+                 ph ? "three-wave" : "wave", (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
                  (double)stream.size() / 1e6);
   return GMG_OK;
 }
@@ -2208,6 +2334,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "coarse_chunk") ctx->coarse_chunk = (int)value;
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
+  else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
   else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }

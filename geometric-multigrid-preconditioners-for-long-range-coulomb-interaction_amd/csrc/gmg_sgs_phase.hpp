@@ -1,0 +1,273 @@
+// gmg_sgs_phase.hpp -- the SSOR wavefront sweep of gmg_sgs.hpp with the dependent steps taken in turn by THREE waves.
+//
+// Reference: LA::MPI::PreconditionSSOR with AdditionalData(0.5), /root/reference/src/step-50.cc:970-973 (same
+// arithmetic, same order as gmg_sgs.hpp and oracle/gmg_oracle.c:smoother_apply_inverse).
+//
+// One wave pays ~1000 cycles per dependent step although the step's true dependence is short: of the ~14 products a
+// row adds, only the few whose column was updated by the PREVIOUS step cannot be formed in advance.  So a row's sum
+// is cut where its first such column stands (CSR order is kept): the HEAD -- everything before it -- needs nothing
+// from the previous step, the TAIL is that column and whatever follows it.  Three waves of one workgroup take the
+// steps in turn and meet at s_barrier once per PHASE; in phase p
+//     wave p % 3       finishes step p       (CRIT: gathers the tail's y, continues the sum, writes the new y to LDS),
+//     wave (p+1) % 3   prepares step p + 1   (P2: gathers the head's y, forms the head's partial sum),
+//     wave (p+2) % 3   fetches step p + 2    (P1: the step's records from its LDS region into registers, then starts
+//                                             the copy of its NEXT block, step p + 5, global -> LDS),
+// so that the dependent chain is barrier -> <= L gathers -> L multiply-adds -> one LDS store -> barrier.  The records
+// reach LDS by global_load_lds (no registers, no helper waves); a fourth wave touches the stream ~64 KB ahead so that
+// those copies hit the L2.  Nobody spins: every wave executes exactly n_steps + 2 barriers per range.
+//
+// Forward sweep (columns j < i): the tail is short (level 1 of the 64 k-atom hierarchy: <= 11 entries per step, mean
+// 5), the head up to 24.  Backward sweep (columns j >= i, continuing the forward sum): the late columns are the
+// nearest upper neighbours, which come FIRST in CSR order, so nearly the whole row is tail (~22): the backward sweep
+// gains less.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gmg_sgs.hpp"
+
+namespace gmg {
+
+constexpr int kPhRegion = 16384;  // bytes of LDS per compute wave for the block it is reading (a block never exceeds it)
+constexpr int kPhMaxRows = 32;    // rows per step
+constexpr int kPhMaxEntries = 36; // 8 G + L of a range
+constexpr int kPhThreads = 256;   // waves 0..2 compute, wave 3 prefetches
+constexpr int kPhJunk = 256;      // LDS bytes the prefetch wave's copies land in
+constexpr int kPhYSlots = (160 * 1024 - 3 * kPhRegion - kPhJunk) / 8 & ~1;  // doubles of y in LDS: 14304
+__host__ __device__ constexpr bool ph_shape_ok(int g, int l) { return g >= 0 && g <= 3 && l >= 4 && l <= 28 && l % 4 == 0 && 8 * g + l <= kPhMaxEntries; }
+__host__ __device__ constexpr int ph_stride(int g, int l) {
+  const int s = 32 + 96 * g + 12 * l;  // multiple of 16 (l is a multiple of 4)
+  return (s / 16) % 2 ? s : s + 16;    // odd multiple of 16: 16-byte LDS reads of consecutive lanes hit distinct banks
+}
+
+// One range = consecutive steps of one sweep direction whose working set fits the LDS.  A step's block: 16-byte
+// header {nrows, bytes of the block three steps on (0: none), its offset in the range's stream, -}, then one record
+// per row:  +0 r  +8 1/a_ii  +16 prefix (backward: the forward sweep's sum)  +24 u32 LDS address of the row's y
+//           +28 u32 aux (forward: index, in doubles, of the prefix field of the row's backward record)
+//           +32 head values [8 G]   tail values [L]   head LDS addresses u32 [8 G]   tail LDS addresses u32 [L]
+// (padding: value +0.0, address = the row's own y).
+struct PhRange {
+  int64_t stream_off;
+  int32_t n_steps, ws_off, n_own, n_ws, backward, G, L;
+  uint32_t blk_off[3], blk_bytes[3];  // the first three blocks
+  uint32_t pf_lead, pf_step;          // prefetch wave: bytes ahead at phase 0, bytes per phase (multiples of 128)
+  uint32_t stream_bytes, pad;
+};
+
+struct SgsPhaseArgs {
+  const PhRange *ranges;
+  const int32_t *block_rng;
+  int block0;
+  char *stream;
+  const int32_t *ws_ci, *ci_row;
+  double *ycur, *y;
+  double omega;
+  int y_slots;
+  unsigned long long *prof;  // per range {cycles of the phase loop, working-set load, write-back, -} (null: off)
+};
+
+namespace ph {
+
+using sw::lds_ld;
+using sw::lds_st;
+using sw::u32x4;
+using sw::f64x2;
+
+__device__ __forceinline__ void bar() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my LDS stores are done before the others are released
+  __builtin_amdgcn_s_barrier();
+}
+
+// bytes [0, bytes) of src -> LDS at dst, 1 KB per instruction (may copy up to 1008 bytes beyond: the stream is padded)
+__device__ __forceinline__ void copy_to_lds(const char *src, uint32_t dst, uint32_t bytes, int lane) {
+  const char *s = src + lane * 16;
+  for (uint32_t o = 0; o < bytes; o += 1024)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s + o),
+                                     (__attribute__((address_space(3))) void *)(uintptr_t)(dst + o), 16, 0, 0);
+}
+
+template <int G, int L>
+struct Rec {
+  double hv[G > 0 ? 8 * G : 1], tv[L];
+  uint32_t ha[G > 0 ? 8 * G : 1], ta[L];
+  double r, invd, prefix, yold, acc;
+  uint32_t my, aux;
+  int nrows;
+};
+
+template <int G, int L, bool FWD>
+__device__ __forceinline__ void sweep(const PhRange *R, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega) {
+  constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
+  const int n = R->n_steps;
+  const char *base = stream + R->stream_off;
+  Rec<G, L> C;
+  int t = w;
+  if (t < n) copy_to_lds(base + R->blk_off[w], region, R->blk_bytes[w], lane);
+  for (int i = 0; i < w; ++i) bar();
+  int done = w;
+  while (t < n) {
+    // ---- P1: my block has arrived (the only copies in flight in front of it are older); records -> registers
+    if (FWD && t != w) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): the prefix store of my last step may still be on its way
+    else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
+    {
+      const u32x4 hdr = lds_ld<u32x4>(region);
+      C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
+      const uint32_t nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y), nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);
+      const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
+      const f64x2 ri = lds_ld<f64x2>(rec);
+      const u32x4 q = lds_ld<u32x4>(rec + 16);
+      C.r = ri.x; C.invd = ri.y;
+      C.prefix = __hiloint2double((int)q.y, (int)q.x);
+      C.my = q.z; C.aux = q.w;
+#pragma unroll
+      for (int j = 0; j < 4 * G; ++j) {
+        const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
+        C.hv[2 * j] = a2.x; C.hv[2 * j + 1] = a2.y;
+      }
+#pragma unroll
+      for (int j = 0; j < L / 2; ++j) {
+        const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 64 * G + 16 * j);
+        C.tv[2 * j] = a2.x; C.tv[2 * j + 1] = a2.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * G; ++j) {
+        const u32x4 c = lds_ld<u32x4>(rec + 32 + 64 * G + 8 * L + 16 * j);
+        C.ha[4 * j] = c.x; C.ha[4 * j + 1] = c.y; C.ha[4 * j + 2] = c.z; C.ha[4 * j + 3] = c.w;
+      }
+#pragma unroll
+      for (int j = 0; j < L / 4; ++j) {
+        const u32x4 c = lds_ld<u32x4>(rec + 32 + 96 * G + 8 * L + 16 * j);
+        C.ta[4 * j] = c.x; C.ta[4 * j + 1] = c.y; C.ta[4 * j + 2] = c.z; C.ta[4 * j + 3] = c.w;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the region is done: it may be overwritten
+      if (nx_bytes) copy_to_lds(base + nx_off, region, nx_bytes, lane);
+    }
+    bar();
+    // ---- P2: the head (no column of it is written in this phase or the next)
+    {
+      double yh[G > 0 ? 8 * G : 1];
+#pragma unroll
+      for (int k = 0; k < 8 * G; ++k) yh[k] = lds_ld<double>(C.ha[k]);
+      C.yold = 0.0;
+      if constexpr (!FWD) C.yold = lds_ld<double>(C.my);
+      double acc = FWD ? 0.0 : C.prefix;
+#pragma unroll
+      for (int k = 0; k < 8 * G; ++k) acc += C.hv[k] * yh[k];
+      C.acc = acc;
+    }
+    bar();
+    // ---- CRIT: the tail
+    {
+      double yt[L];
+#pragma unroll
+      for (int k = 0; k < L; ++k) yt[k] = lds_ld<double>(C.ta[k]);
+      double acc = C.acc;
+#pragma unroll
+      for (int k = 0; k < L; ++k) acc += C.tv[k] * yt[k];
+      if (lane < C.nrows) {
+        lds_st<double>(C.my, C.yold + (omega * (C.r - acc)) * C.invd);
+        if constexpr (FWD) stream_d[C.aux] = acc;
+      }
+    }
+    bar();
+    t += 3;
+    done += 3;
+  }
+  for (; done < n + 2; ++done) bar();
+}
+
+template <bool FWD>
+__device__ __forceinline__ void dispatch(const PhRange *R, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega) {
+#define PH_CASE(g, l) \
+  case (g) * 8 + (l) / 4: sweep<g, l, FWD>(R, stream, stream_d, region, w, lane, omega); break;
+  switch (R->G * 8 + R->L / 4) {
+    PH_CASE(0, 4) PH_CASE(0, 8) PH_CASE(0, 12) PH_CASE(0, 16) PH_CASE(0, 20) PH_CASE(0, 24) PH_CASE(0, 28)
+    PH_CASE(1, 4) PH_CASE(1, 8) PH_CASE(1, 12) PH_CASE(1, 16) PH_CASE(1, 20) PH_CASE(1, 24) PH_CASE(1, 28)
+    PH_CASE(2, 4) PH_CASE(2, 8) PH_CASE(2, 12) PH_CASE(2, 16) PH_CASE(2, 20)
+    PH_CASE(3, 4) PH_CASE(3, 8) PH_CASE(3, 12)
+    default: break;  // (the host builds no other shape; the barriers below stay matched because every wave takes this branch)
+  }
+#undef PH_CASE
+}
+
+}  // namespace ph
+
+__global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // at LDS address 0: [y slots][3 regions][junk]
+  double *ylds = reinterpret_cast<double *>(lds);
+  const uint32_t ring0 = (uint32_t)a.y_slots * 8u;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r_begin = a.block_rng[a.block0 + blockIdx.x], r_end = a.block_rng[a.block0 + blockIdx.x + 1];
+  for (int rg = r_begin; rg < r_end; ++rg) {
+    const PhRange *Rp = a.ranges + rg;
+    struct { int n_steps, ws_off, n_own, n_ws, backward, G, L; uint32_t pf_lead, pf_step, stream_bytes; int64_t stream_off; } R;
+    R.n_steps = Rp->n_steps; R.ws_off = Rp->ws_off; R.n_own = Rp->n_own; R.n_ws = Rp->n_ws; R.backward = Rp->backward; R.G = Rp->G; R.L = Rp->L;
+    R.pf_lead = Rp->pf_lead; R.pf_step = Rp->pf_step; R.stream_bytes = Rp->stream_bytes; R.stream_off = Rp->stream_off;
+    const int32_t *ws = a.ws_ci + R.ws_off;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (a.prof) t0 = __builtin_amdgcn_s_memtime();
+    for (int k0 = tid; k0 < R.n_ws; k0 += 8 * kPhThreads) {  // eight independent gathers in flight per thread
+      int ci[8];
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ci[j] = k0 + j * kPhThreads < R.n_ws ? ws[k0 + j * kPhThreads] : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ci[j] >= 0 ? a.ycur[ci[j]] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (ci[j] >= 0) ylds[k0 + j * kPhThreads] = v[j];
+    }
+    __syncthreads();
+    if (a.prof) t1 = __builtin_amdgcn_s_memtime();
+    if (!ph_shape_ok(R.G, R.L)) {
+      // (the host builds no other shape)
+    } else if (wid < 3) {
+      double *stream_d = reinterpret_cast<double *>(a.stream);
+      const uint32_t region = ring0 + (uint32_t)wid * (uint32_t)kPhRegion;
+      if (R.backward) ph::dispatch<false>(Rp, a.stream, stream_d, region, wid, lane, a.omega);
+      else ph::dispatch<true>(Rp, a.stream, stream_d, region, wid, lane, a.omega);
+    } else {
+      // prefetch wave: one 4-byte copy per 128-byte line, pf_step bytes per phase, into the junk area
+      const char *base = a.stream + R.stream_off;
+      const uint32_t junk = ring0 + 3u * (uint32_t)kPhRegion;
+      uint32_t cur = 0;
+      const uint32_t first = min(R.pf_lead, R.stream_bytes);
+      for (; cur < first; cur += 8192)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + min(cur + (uint32_t)lane * 128u, R.stream_bytes - 4u)),
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)junk, 4, 0, 0);
+      for (int p = 0; p < R.n_steps + 2; ++p) {
+        const uint32_t end = min(cur + R.pf_step, R.stream_bytes);
+        for (; cur < end; cur += 8192)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + min(cur + (uint32_t)lane * 128u, R.stream_bytes - 4u)),
+                                           (__attribute__((address_space(3))) void *)(uintptr_t)junk, 4, 0, 0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): prefix stores, leftover copies
+    __syncthreads();
+    if (a.prof) t2 = __builtin_amdgcn_s_memtime();
+    for (int k0 = tid; k0 < R.n_own; k0 += 8 * kPhThreads) {
+      int ci[8], row[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? ws[k0 + j * kPhThreads] : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = (R.backward && ci[j] >= 0) ? a.ci_row[ci[j]] : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (ci[j] >= 0) {
+          const double v = ylds[k0 + j * kPhThreads];
+          a.ycur[ci[j]] = v;
+          if (row[j] >= 0) a.y[row[j]] = v;
+        }
+    }
+    __syncthreads();
+    if (a.prof) {
+      t3 = __builtin_amdgcn_s_memtime();
+      if (tid == 0) {
+        unsigned long long *o = a.prof + 4 * (size_t)rg;
+        o[0] = t2 - t1; o[1] = 0; o[2] = t1 - t0; o[3] = t3 - t2;
+      }
+    }
+  }
+}
+
+}  // namespace gmg

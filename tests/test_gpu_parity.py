@@ -237,12 +237,13 @@ def test_single_rank_communicator_path(hier45):
     c.close()
 
 
-@pytest.mark.parametrize("blocks,variant", [(1, "wave"), (3, "wave"), (16, "wave"), (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
+@pytest.mark.parametrize("blocks,variant", [(1, "phase"), (3, "phase"), (16, "phase"), (1, "phase-ranges"), (3, "phase-ranges"), (1, "wave"), (3, "wave"), (16, "wave"),
+                                            (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
 def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the device
-    variants: the wavefront sweep with y in LDS (gmg_sgs.hpp) with a block's rows in one LDS range, the same
-    with the LDS budget cut to 300 doubles so that every block is swept in many ranges (working sets written
-    back / reloaded in between), and the generic CSR sweep."""
+    variants: the three-wave sweep (gmg_sgs_phase.hpp, the default) and the one-wave sweep (gmg_sgs.hpp), each with a
+    block's rows in one LDS range and with the LDS budget cut to 300 doubles so that every block is swept in many
+    ranges (working sets written back / reloaded in between), and the generic CSR sweep."""
     level = 4
     n = hier3.level_matrices[level].n_rows
     rng = np.random.default_rng(7)
@@ -250,7 +251,9 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     mg = go.OracleMG(hier3, smoother=go.SSOR, ssor_blocks=blocks)
     c = capi().Context(len(hier3.level_matrices))
     c.set_tuning(ssor_blocks=blocks)
-    if variant == "ranges":
+    if variant in ("wave", "ranges"):
+        c.set_option("sgs_disable_phase", 1)
+    if variant.endswith("ranges"):
         c.set_option("sgs_y_slots", 300)
     if variant == "sweep":
         c.set_option("sgs_disable_wave", 1)
