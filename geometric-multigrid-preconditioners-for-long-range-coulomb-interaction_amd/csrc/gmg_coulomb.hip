@@ -80,6 +80,8 @@ struct SgsPlan {
   // three-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
   bool phased = false;
   PhRange *p_ranges = nullptr;
+  uint2 *p_blk_tab = nullptr;
+  std::vector<PhRange> host_pranges;
 };
 
 struct Level {
@@ -141,6 +143,7 @@ struct gmg_context {
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
   bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
+  int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the three-wave sweep (value - 1: timing experiment)
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
   bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false;
@@ -802,8 +805,30 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
       const size_t lds = ctx->sgs_lds_bytes_override > 0 ? (size_t)ctx->sgs_lds_bytes_override : (size_t)L.sgs.w_lds_bytes;
       if (L.sgs.phased) {
         SgsPhaseArgs q{};
-        q.ranges = L.sgs.p_ranges; q.block_rng = p.block_rng; q.block0 = p.block0; q.stream = p.stream; q.ws_ci = p.ws_ci; q.ci_row = p.ci_row;
+        q.ranges = L.sgs.p_ranges; q.blk_tab = L.sgs.p_blk_tab; q.block_rng = p.block_rng; q.block0 = p.block0; q.stream = p.stream; q.ws_ci = p.ws_ci; q.ci_row = p.ci_row;
         q.ycur = p.ycur; q.y = p.y; q.omega = p.omega; q.y_slots = p.y_slots; q.prof = nullptr;
+        if (ctx->sgs_phase_profile > 0) {
+          const size_t nr = (size_t)L.sgs.w_n_ranges;
+          unsigned long long *d = nullptr;
+          std::vector<unsigned long long> h(12 * nr, 0);
+          HIPC(hipMalloc(&d, sizeof(unsigned long long) * 12 * nr));
+          q.prof = d; q.mode = ctx->sgs_phase_profile - 1;
+          hipLaunchKernelGGL(sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
+          HIPC(hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream));
+          HIPC(hipStreamSynchronize(ctx->stream));
+          (void)hipFree(d);
+          if (L.sgs.w_steps > 1000 && nbl == 1) {
+            std::fprintf(stderr, "[gmg] three-wave sweep, mode %d, %lld rows: per range dir G L steps | cycles/step | load+write-back cycles\n", q.mode, (long long)L.n);
+            for (size_t i = 0; i < nr; ++i) {
+              const PhRange &P = L.sgs.host_pranges[i];
+              const double turns = std::max(1.0, P.n_steps / 3.0);
+              std::fprintf(stderr, "[gmg]   %s G %d L %2d steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.G, P.L, P.n_steps,
+                           (double)h[12 * i] / std::max(1, P.n_steps), h[12 * i + 2] + h[12 * i + 3], h[12 * i + 4] / turns, h[12 * i + 5] / turns, h[12 * i + 6] / turns, h[12 * i + 7] / turns,
+                           h[12 * i + 8] / turns, h[12 * i + 9] / turns);
+            }
+          }
+          return GMG_OK;
+        }
         launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
       } else {
         launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
@@ -1154,7 +1179,7 @@ int setup_diag(gmg_context *ctx, int64_t n, const int64_t *rp, const int32_t *co
 void free_sgs(SgsPlan &g) {
   for (void *p : {(void *)g.stage_ptr, (void *)g.stage_rows, (void *)g.block_row, (void *)g.block_stage, (void *)g.w_ranges,
                   (void *)g.w_block_rng, (void *)g.w_ws_ci, (void *)g.w_ci_row, (void *)g.w_row_ci, (void *)g.w_rpos_f, (void *)g.w_rpos_b,
-                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd, (void *)g.w_stage, (void *)g.p_ranges})
+                  (void *)g.w_stream, (void *)g.w_ycur, (void *)g.w_iso_diag, (void *)g.w_iso_invd, (void *)g.w_stage, (void *)g.p_ranges, (void *)g.p_blk_tab})
     if (p) (void)hipFree(p);
   g = SgsPlan();
 }
@@ -1175,6 +1200,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : y_max;
   y_cap = std::max(64, std::min(y_cap, y_max)) & ~1;
   std::vector<PhRange> pranges;
+  std::vector<uint2> blk_tab;
   std::vector<int32_t> row_ci((size_t)n, -1), ci_row, rpos_f, rpos_b, ws_ci, block_rng((size_t)n_blocks + 1, 0);
   std::vector<double> iso_diag((size_t)n, 0.0), iso_invd((size_t)n, 1.0);
   std::vector<SwRange> ranges;
@@ -1430,10 +1456,11 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             }
             off += (raw + 15) / 16 * 16;
           }
+          P.blk_tab = (uint32_t)blk_tab.size();
           for (size_t q = 0; q < boff.size(); ++q) {
+            blk_tab.push_back(uint2{(uint32_t)boff[q], (uint32_t)bbytes[q]});
             uint32_t *h = reinterpret_cast<uint32_t *>(stream.data() + base + boff[q]);
-            if (q + 3 < boff.size()) { h[1] = (uint32_t)bbytes[q + 3]; h[2] = (uint32_t)boff[q + 3]; }
-            if (q < 3) { P.blk_off[q] = (uint32_t)boff[q]; P.blk_bytes[q] = (uint32_t)bbytes[q]; }
+            if (q + 3 < boff.size()) { h[1] = (uint32_t)bbytes[q + 3]; h[2] = (uint32_t)boff[q + 3]; }  // the block its reader copies next
           }
           const int64_t padded = (off + 2048 + 1023) / 1024 * 1024;  // the copies read whole KB: up to 1008 bytes beyond a block
           if (padded >= ((int64_t)1 << 31) || (base + padded) / 8 >= ((int64_t)1 << 31)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1533,6 +1560,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
   SW_UP(G.w_ranges, ranges, SwRange)
   SW_UP(G.p_ranges, pranges, PhRange)
+  SW_UP(G.p_blk_tab, blk_tab, uint2)
   SW_UP(G.w_block_rng, block_rng, int32_t)
   SW_UP(G.w_ws_ci, ws_ci, int32_t)
   SW_UP(G.w_ci_row, ci_row, int32_t)
@@ -1560,6 +1588,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   G.w_lds_bytes = ph ? y_slots * 8 + 3 * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
   G.w_n_ranges = (int)(ph ? pranges.size() : ranges.size());
   G.phased = ph;
+  G.host_pranges = pranges;
   G.w_n_coupled = (int64_t)ci_row.size();
   G.w_stream_bytes = (int64_t)stream.size();
   G.w_steps = total_steps; G.w_stages = total_stages;
@@ -2335,6 +2364,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
+  else if (k == "sgs_phase_profile") ctx->sgs_phase_profile = (int)value;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
   else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }

@@ -30,7 +30,7 @@ namespace gmg {
 constexpr int kPhRegion = 16384;  // bytes of LDS per compute wave for the block it is reading (a block never exceeds it)
 constexpr int kPhMaxRows = 32;    // rows per step
 constexpr int kPhMaxEntries = 36; // 8 G + L of a range
-constexpr int kPhThreads = 256;   // waves 0..2 compute, wave 3 prefetches
+constexpr int kPhThreads = 256;   // waves 0..2 compute, wave 3 prefetches the records into the L2
 constexpr int kPhJunk = 256;      // LDS bytes the prefetch wave's copies land in
 constexpr int kPhYSlots = (160 * 1024 - 3 * kPhRegion - kPhJunk) / 8 & ~1;  // doubles of y in LDS: 14304
 __host__ __device__ constexpr bool ph_shape_ok(int g, int l) { return g >= 0 && g <= 3 && l >= 4 && l <= 28 && l % 4 == 0 && 8 * g + l <= kPhMaxEntries; }
@@ -48,7 +48,7 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 struct PhRange {
   int64_t stream_off;
   int32_t n_steps, ws_off, n_own, n_ws, backward, G, L;
-  uint32_t blk_off[3], blk_bytes[3];  // the first three blocks
+  uint32_t blk_tab, pad0[5];          // first entry of the range in the block table
   uint32_t pf_lead, pf_step;          // prefetch wave: bytes ahead at phase 0, bytes per phase (multiples of 128)
   uint32_t stream_bytes, pad;
 };
@@ -58,11 +58,13 @@ struct SgsPhaseArgs {
   const int32_t *block_rng;
   int block0;
   char *stream;
+  const uint2 *blk_tab;      // per step {offset in its range's stream, bytes}
   const int32_t *ws_ci, *ci_row;
   double *ycur, *y;
   double omega;
   int y_slots;
   unsigned long long *prof;  // per range {cycles of the phase loop, working-set load, write-back, -} (null: off)
+  int mode;                  // timing experiments (wrong results): 1 no tail chain, 2 no tail gathers, 3 no head work, 4 no record copies after the first
 };
 
 namespace ph {
@@ -73,16 +75,50 @@ using sw::u32x4;
 using sw::f64x2;
 
 __device__ __forceinline__ void bar() {
+  asm volatile("" ::: "memory");       // (the compiler moves no LDS access across a phase boundary)
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my LDS stores are done before the others are released
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
-// bytes [0, bytes) of src -> LDS at dst, 1 KB per instruction (may copy up to 1008 bytes beyond: the stream is padded)
+// bytes [0, bytes) of src -> LDS at dst, 1 KB per instruction (may copy up to 1008 bytes beyond: the stream is padded).
+// Straight-line: a lone wave pays ~35 cycles for every taken branch, so the loop is unrolled over the at most
+// kPhRegion / 1024 pieces and left by one forward branch; uniform base + the lane's 32-bit offset.
 __device__ __forceinline__ void copy_to_lds(const char *src, uint32_t dst, uint32_t bytes, int lane) {
-  const char *s = src + lane * 16;
-  for (uint32_t o = 0; o < bytes; o += 1024)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s + o),
-                                     (__attribute__((address_space(3))) void *)(uintptr_t)(dst + o), 16, 0, 0);
+  const char *s = src + (uint32_t)lane * 16u;
+#pragma unroll
+  for (int k = 0; k < kPhRegion / 4096; ++k) {  // four pieces share one address register and one M0 value (immediate offsets)
+    if ((uint32_t)k * 4096u >= bytes) break;
+    const auto *g = (const __attribute__((address_space(1))) void *)(s + k * 4096);
+    auto *l = (__attribute__((address_space(3))) void *)(uintptr_t)(dst + (uint32_t)k * 4096u);
+    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    if ((uint32_t)k * 4096u + 1024u < bytes) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+    if ((uint32_t)k * 4096u + 2048u < bytes) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+    if ((uint32_t)k * 4096u + 3072u < bytes) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+  }
+}
+
+// waits until at most k vector-memory operations of this wave are in flight (k: wave-uniform, 0..16)
+__device__ __forceinline__ void wait_all_but(int k) {
+  switch (k) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
+    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
+    case 13: __builtin_amdgcn_s_waitcnt(0x0f7d); break;
+    case 14: __builtin_amdgcn_s_waitcnt(0x0f7e); break;
+    case 15: __builtin_amdgcn_s_waitcnt(0x0f7f); break;
+    default: __builtin_amdgcn_s_waitcnt(0x4f70); break;  // vmcnt(16)
+  }
 }
 
 template <int G, int L>
@@ -95,23 +131,28 @@ struct Rec {
 };
 
 template <int G, int L, bool FWD>
-__device__ __forceinline__ void sweep(const PhRange *R, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega) {
+__device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
   constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
   const int n = R->n_steps;
   const char *base = stream + R->stream_off;
   Rec<G, L> C;
   int t = w;
-  if (t < n) copy_to_lds(base + R->blk_off[w], region, R->blk_bytes[w], lane);
+  if (t < n) { const uint2 e = tab[t]; copy_to_lds(base + e.x, region, e.y, lane); }
   for (int i = 0; i < w; ++i) bar();
   int done = w;
+  uint2 nxt{0u, 0u};
+  unsigned long long c_wait = 0, c_p1 = 0, c_copy = 0, c_p2 = 0, c_crit = 0, c_bar = 0, m0 = 0, m1 = 0;
+#define PH_T(acc) if (tp) { m1 = __builtin_amdgcn_s_memtime(); acc += m1 - m0; m0 = m1; }
+  if (tp) m0 = __builtin_amdgcn_s_memtime();
   while (t < n) {
-    // ---- P1: my block has arrived (the only copies in flight in front of it are older); records -> registers
-    if (FWD && t != w) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): the prefix store of my last step may still be on its way
+    // ---- P1: records -> registers
+    if (FWD && t != w) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): my block has arrived; the prefix store of my last step may be on its way
     else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
+    PH_T(c_wait)
     {
       const u32x4 hdr = lds_ld<u32x4>(region);
       C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
-      const uint32_t nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y), nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);
+      nxt.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); nxt.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 3
       const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
       const f64x2 ri = lds_ld<f64x2>(rec);
       const u32x4 q = lds_ld<u32x4>(rec + 16);
@@ -139,10 +180,14 @@ __device__ __forceinline__ void sweep(const PhRange *R, const char *stream, doub
         C.ta[4 * j] = c.x; C.ta[4 * j + 1] = c.y; C.ta[4 * j + 2] = c.z; C.ta[4 * j + 3] = c.w;
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the region is done: it may be overwritten
-      if (nx_bytes) copy_to_lds(base + nx_off, region, nx_bytes, lane);
+      PH_T(c_p1)
     }
     bar();
-    // ---- P2: the head (no column of it is written in this phase or the next)
+    PH_T(c_bar)
+    // ---- P2: starts the copy of my next block (three phases before it is read), then the head
+    if (nxt.y) copy_to_lds(base + nxt.x, region, nxt.y, lane);
+    PH_T(c_copy)
+    // (no column of the head is written in this phase or the next)
     {
       double yh[G > 0 ? 8 * G : 1];
 #pragma unroll
@@ -152,9 +197,12 @@ __device__ __forceinline__ void sweep(const PhRange *R, const char *stream, doub
       double acc = FWD ? 0.0 : C.prefix;
 #pragma unroll
       for (int k = 0; k < 8 * G; ++k) acc += C.hv[k] * yh[k];
+      asm volatile("" : "+v"(acc));  // formed here, not after the barrier (the compiler would sink the chain into CRIT)
       C.acc = acc;
     }
+    PH_T(c_p2)
     bar();
+    PH_T(c_bar)
     // ---- CRIT: the tail
     {
       double yt[L];
@@ -168,17 +216,22 @@ __device__ __forceinline__ void sweep(const PhRange *R, const char *stream, doub
         if constexpr (FWD) stream_d[C.aux] = acc;
       }
     }
+    if (tp) { __builtin_amdgcn_s_waitcnt(0xc07f); }
+    PH_T(c_crit)
     bar();
+    PH_T(c_bar)
     t += 3;
     done += 3;
   }
   for (; done < n + 2; ++done) bar();
+  if (tp && w == 0 && lane == 0) { tp[0] = c_wait; tp[1] = c_p1; tp[2] = c_copy; tp[3] = c_p2; tp[4] = c_crit; tp[5] = c_bar; }
+#undef PH_T
 }
 
 template <bool FWD>
-__device__ __forceinline__ void dispatch(const PhRange *R, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega) {
+__device__ __forceinline__ void dispatch(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
 #define PH_CASE(g, l) \
-  case (g) * 8 + (l) / 4: sweep<g, l, FWD>(R, stream, stream_d, region, w, lane, omega); break;
+  case (g) * 8 + (l) / 4: sweep<g, l, FWD>(R, tab, stream, stream_d, region, w, lane, omega, tp); break;
   switch (R->G * 8 + R->L / 4) {
     PH_CASE(0, 4) PH_CASE(0, 8) PH_CASE(0, 12) PH_CASE(0, 16) PH_CASE(0, 20) PH_CASE(0, 24) PH_CASE(0, 28)
     PH_CASE(1, 4) PH_CASE(1, 8) PH_CASE(1, 12) PH_CASE(1, 16) PH_CASE(1, 20) PH_CASE(1, 24) PH_CASE(1, 28)
@@ -223,8 +276,8 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     } else if (wid < 3) {
       double *stream_d = reinterpret_cast<double *>(a.stream);
       const uint32_t region = ring0 + (uint32_t)wid * (uint32_t)kPhRegion;
-      if (R.backward) ph::dispatch<false>(Rp, a.stream, stream_d, region, wid, lane, a.omega);
-      else ph::dispatch<true>(Rp, a.stream, stream_d, region, wid, lane, a.omega);
+      if (R.backward) ph::dispatch<false>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
+      else ph::dispatch<true>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
     } else {
       // prefetch wave: one 4-byte copy per 128-byte line, pf_step bytes per phase, into the junk area
       const char *base = a.stream + R.stream_off;
@@ -263,7 +316,7 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     if (a.prof) {
       t3 = __builtin_amdgcn_s_memtime();
       if (tid == 0) {
-        unsigned long long *o = a.prof + 4 * (size_t)rg;
+        unsigned long long *o = a.prof + 12 * (size_t)rg;
         o[0] = t2 - t1; o[1] = 0; o[2] = t1 - t0; o[3] = t3 - t2;
       }
     }
