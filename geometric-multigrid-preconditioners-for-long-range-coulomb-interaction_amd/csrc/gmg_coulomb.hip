@@ -143,6 +143,7 @@ struct gmg_context {
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
   bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
+  bool sgs_phase_nosplit = false;  // the whole tail is gathered in the dependent phase (comparison / tests)
   int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the three-wave sweep (value - 1: timing experiment)
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
@@ -821,8 +822,8 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
             std::fprintf(stderr, "[gmg] three-wave sweep, mode %d, %lld rows: per range dir G L steps | cycles/step | load+write-back cycles\n", q.mode, (long long)L.n);
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
-              const double turns = std::max(1.0, P.n_steps / 3.0);
-              std::fprintf(stderr, "[gmg]   %s G %d L %2d steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.G, P.L, P.n_steps,
+              const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
+              std::fprintf(stderr, "[gmg]   %s G %d L1 %2d L2 %2d steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.G, (int)P.L1, P.L - (int)P.L1, P.n_steps,
                            (double)h[12 * i] / std::max(1, P.n_steps), h[12 * i + 2] + h[12 * i + 3], h[12 * i + 4] / turns, h[12 * i + 5] / turns, h[12 * i + 6] / turns, h[12 * i + 7] / turns,
                            h[12 * i + 8] / turns, h[12 * i + 9] / turns);
             }
@@ -1387,28 +1388,58 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               step_of[(size_t)seq[(size_t)(steps[st].first + u)]] = (int32_t)(st - s0);
               upd_stamp[(size_t)seq[(size_t)(steps[st].first + u)]] = stamp_id;
             }
-          int max_tail = 0, max_n = 0;
-          std::vector<int32_t> tail_of;  // per row of the range, in step order
+          // per row (in step order): entries, index of the first and of the last late column (ne: none)
+          struct RowCut { int32_t ne, first, last; };
+          std::vector<RowCut> cut;
           for (size_t st = s0; st < s1; ++st)
             for (int u = 0; u < steps[st].nrows; ++u) {
               const int i = seq[(size_t)(steps[st].first + u)];
-              int ne = 0, first_late = -1;
+              int ne = 0, first_late = -1, last_late = -1;
               for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
                 const int c = pcol[(size_t)k];
                 if (!in_dir(i, c)) continue;
-                if (first_late < 0 && c != i && upd_stamp[(size_t)c] == stamp_id && step_of[(size_t)c] == (int32_t)(st - s0) - 1) first_late = ne;
+                if (c != i && upd_stamp[(size_t)c] == stamp_id && step_of[(size_t)c] == (int32_t)(st - s0) - 1) {
+                  if (first_late < 0) first_late = ne;
+                  last_late = ne;
+                }
                 ++ne;
               }
-              const int tl = first_late < 0 ? 0 : ne - first_late;
-              tail_of.push_back(tl);
-              max_tail = std::max(max_tail, tl); max_n = std::max(max_n, ne);
+              if (first_late < 0) { first_late = ne; last_late = ne - 1; }
+              cut.push_back(RowCut{ne, first_late, last_late});
             }
-          const int Lr = std::max(4, (max_tail + 3) / 4 * 4);
-          const int Gr = (std::max(0, max_n - Lr) + 7) / 8;
-          if (!ph_shape_ok(Gr, Lr)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+          // shape: head (8 G) | T1 (L1: from the first late column to the last, gathered in the dependent phase) | T2 (L2: behind
+          // the last late column, products formed ahead).  A row may give the end of its head and the start of its T2 to T1;
+          // of the shapes every row of the range fits, the one with the cheapest phase (measured costs, cycles) is taken.
+          auto fits = [&](const RowCut &rc, int g, int l1, int l2, int *h0o, int *h1o) {
+            const int h1 = std::max(rc.last + 1, rc.ne - l2), h0 = std::max(std::min(rc.first, 8 * g), h1 - l1);
+            if (h0 > rc.first || h0 > 8 * g || h0 < 0) return false;
+            if (h0o) { *h0o = h0; *h1o = h1; }
+            return true;
+          };
+          int Gr = -1, L1r = 0, L2r = 0;
+          {
+            const double avg_rows = (double)cut.size() / (double)(s1 - s0);
+            double best = 1e300;
+            for (int g = 0; g <= 3; ++g)
+              for (int l1 = 4; l1 <= 28; l1 += 4)
+                for (int l2 = 0; l2 <= 24; l2 += 8) {
+                  if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
+                  bool ok = true;
+                  for (const RowCut &rc : cut)
+                    if (!fits(rc, g, l1, l2, nullptr, nullptr)) { ok = false; break; }
+                  if (!ok) continue;
+                  const int ent = 8 * g + l1 + l2;
+                  const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + avg_rows * ph_stride(g, l1 + l2)) / 1024.0,
+                               p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
+                  const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                  if (cost < best) { best = cost; Gr = g; L1r = l1; L2r = l2; }
+                }
+          }
+          if (Gr < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+          const int Lr = L1r + L2r;
           const int pstride = ph_stride(Gr, Lr);
           PhRange P{};
-          P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir; P.G = Gr; P.L = Lr;
+          P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir; P.G = Gr; P.L = Lr; P.L1 = (uint32_t)L1r;
           P.n_steps = (int32_t)(s1 - s0);
           const int64_t base = ((int64_t)stream.size() + 1023) / 1024 * 1024;
           P.stream_off = base;
@@ -1439,17 +1470,19 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               uint32_t *ha = reinterpret_cast<uint32_t *>(rec + 32 + 64 * Gr + 8 * Lr), *ta = ha + 8 * Gr;
               for (int e = 0; e < 8 * Gr; ++e) { hv[e] = 0.0; ha[e] = my; }
               for (int e = 0; e < Lr; ++e) { tv[e] = 0.0; ta[e] = my; }
-              // the tail: the last max(required, n - 8 G) entries -- never fewer than the columns from the first late one on
-              int ne = 0;
-              for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) ne += in_dir(i, pcol[(size_t)k]);
-              const int tcount = std::max((int)tail_of[tix], std::max(0, ne - 8 * Gr));
-              const int hcount = ne - tcount;
+              const RowCut &rc = cut[tix];
+              const int ne = rc.ne;
+              // head [0, h0), T1 [h0, h1), T2 [h1, ne)
+              int h0 = 0, h1 = ne;
+              (void)fits(rc, Gr, L1r, L2r, &h0, &h1);
               int e = 0;
               for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
                 const int c = pcol[(size_t)k];
                 if (!in_dir(i, c)) continue;
-                if (e < hcount) { hv[e] = pval[(size_t)k]; ha[e] = (uint32_t)slot_of[(size_t)c] * 8u; }
-                else { tv[e - hcount] = pval[(size_t)k]; ta[e - hcount] = (uint32_t)slot_of[(size_t)c] * 8u; }
+                const uint32_t ad = (uint32_t)slot_of[(size_t)c] * 8u;
+                if (e < h0) { hv[e] = pval[(size_t)k]; ha[e] = ad; }
+                else if (e < h1) { tv[e - h0] = pval[(size_t)k]; ta[e - h0] = ad; }
+                else { tv[L1r + e - h1] = pval[(size_t)k]; ta[L1r + e - h1] = ad; }
                 ++e;
               }
               ++tix;
@@ -1460,7 +1493,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           for (size_t q = 0; q < boff.size(); ++q) {
             blk_tab.push_back(uint2{(uint32_t)boff[q], (uint32_t)bbytes[q]});
             uint32_t *h = reinterpret_cast<uint32_t *>(stream.data() + base + boff[q]);
-            if (q + 3 < boff.size()) { h[1] = (uint32_t)bbytes[q + 3]; h[2] = (uint32_t)boff[q + 3]; }  // the block its reader copies next
+            if (q + kPhWaves < boff.size()) { h[1] = (uint32_t)bbytes[q + kPhWaves]; h[2] = (uint32_t)boff[q + kPhWaves]; }  // the block its reader copies next
           }
           const int64_t padded = (off + 2048 + 1023) / 1024 * 1024;  // the copies read whole KB: up to 1008 bytes beyond a block
           if (padded >= ((int64_t)1 << 31) || (base + padded) / 8 >= ((int64_t)1 << 31)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1585,7 +1618,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     }
   }
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = ph ? y_slots * 8 + 3 * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
+  G.w_lds_bytes = ph ? y_slots * 8 + kPhWaves * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
   G.w_n_ranges = (int)(ph ? pranges.size() : ranges.size());
   G.phased = ph;
   G.host_pranges = pranges;
@@ -2365,6 +2398,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
   else if (k == "sgs_phase_profile") ctx->sgs_phase_profile = (int)value;
+  else if (k == "sgs_phase_nosplit") ctx->sgs_phase_nosplit = on;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
   else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }

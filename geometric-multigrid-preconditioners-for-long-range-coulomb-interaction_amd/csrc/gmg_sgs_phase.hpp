@@ -30,10 +30,14 @@ namespace gmg {
 constexpr int kPhRegion = 16384;  // bytes of LDS per compute wave for the block it is reading (a block never exceeds it)
 constexpr int kPhMaxRows = 32;    // rows per step
 constexpr int kPhMaxEntries = 36; // 8 G + L of a range
-constexpr int kPhThreads = 256;   // waves 0..2 compute, wave 3 prefetches the records into the L2
+constexpr int kPhWaves = 4;       // compute waves
+constexpr int kPhThreads = 64 * (kPhWaves + 1);  // waves 0..3 compute, wave 4 prefetches the records into the L2
 constexpr int kPhJunk = 256;      // LDS bytes the prefetch wave's copies land in
-constexpr int kPhYSlots = (160 * 1024 - 3 * kPhRegion - kPhJunk) / 8 & ~1;  // doubles of y in LDS: 14304
-__host__ __device__ constexpr bool ph_shape_ok(int g, int l) { return g >= 0 && g <= 3 && l >= 4 && l <= 28 && l % 4 == 0 && 8 * g + l <= kPhMaxEntries; }
+constexpr int kPhYSlots = (160 * 1024 - kPhWaves * kPhRegion - kPhJunk) / 8 & ~1;  // doubles of y in LDS: 12256
+// a range's shape: 8 g head entries, l1 tail entries gathered in the dependent phase, l2 tail entries whose products are formed ahead
+__host__ __device__ constexpr bool ph_shape_ok(int g, int l1, int l2) {
+  return g >= 0 && g <= 3 && l1 >= 4 && l1 <= 28 && l1 % 4 == 0 && l2 >= 0 && l2 <= 24 && l2 % 8 == 0 && 8 * g + l1 + l2 <= kPhMaxEntries;
+}
 __host__ __device__ constexpr int ph_stride(int g, int l) {
   const int s = 32 + 96 * g + 12 * l;  // multiple of 16 (l is a multiple of 4)
   return (s / 16) % 2 ? s : s + 16;    // odd multiple of 16: 16-byte LDS reads of consecutive lanes hit distinct banks
@@ -47,8 +51,8 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 // (padding: value +0.0, address = the row's own y).
 struct PhRange {
   int64_t stream_off;
-  int32_t n_steps, ws_off, n_own, n_ws, backward, G, L;
-  uint32_t blk_tab, pad0[5];          // first entry of the range in the block table
+  int32_t n_steps, ws_off, n_own, n_ws, backward, G, L;  // L = L1 + L2
+  uint32_t blk_tab, L1, pad0[4];          // first entry of the range in the block table
   uint32_t pf_lead, pf_step;          // prefetch wave: bytes ahead at phase 0, bytes per phase (multiples of 128)
   uint32_t stream_bytes, pad;
 };
@@ -130,8 +134,9 @@ struct Rec {
   int nrows;
 };
 
-template <int G, int L, bool FWD>
+template <int G, int L1, int L2, bool FWD>
 __device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
+  constexpr int L = L1 + L2;
   constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
   const int n = R->n_steps;
   const char *base = stream + R->stream_off;
@@ -152,7 +157,7 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const 
     {
       const u32x4 hdr = lds_ld<u32x4>(region);
       C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
-      nxt.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); nxt.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 3
+      nxt.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); nxt.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
       const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
       const f64x2 ri = lds_ld<f64x2>(rec);
       const u32x4 q = lds_ld<u32x4>(rec + 16);
@@ -184,9 +189,12 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const 
     }
     bar();
     PH_T(c_bar)
-    // ---- P2: starts the copy of my next block (three phases before it is read), then the head
+    // ---- COPY: my next block (step t + 4) global -> LDS; it is read three phases on
     if (nxt.y) copy_to_lds(base + nxt.x, region, nxt.y, lane);
     PH_T(c_copy)
+    bar();
+    PH_T(c_bar)
+    // ---- P2: the head
     // (no column of the head is written in this phase or the next)
     {
       double yh[G > 0 ? 8 * G : 1];
@@ -199,18 +207,30 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const 
       for (int k = 0; k < 8 * G; ++k) acc += C.hv[k] * yh[k];
       asm volatile("" : "+v"(acc));  // formed here, not after the barrier (the compiler would sink the chain into CRIT)
       C.acc = acc;
+      // the tail behind the last late column: its products are formed here, CRIT only adds them
+      double y2[L2 > 0 ? L2 : 1];
+#pragma unroll
+      for (int k = 0; k < L2; ++k) y2[k] = lds_ld<double>(C.ta[L1 + k]);
+#pragma unroll
+      for (int k = 0; k < L2; ++k) {
+        double pr = C.tv[L1 + k] * y2[k];
+        asm volatile("" : "+v"(pr));
+        C.tv[L1 + k] = pr;
+      }
     }
     PH_T(c_p2)
     bar();
     PH_T(c_bar)
     // ---- CRIT: the tail
     {
-      double yt[L];
+      double yt[L1];
 #pragma unroll
-      for (int k = 0; k < L; ++k) yt[k] = lds_ld<double>(C.ta[k]);
+      for (int k = 0; k < L1; ++k) yt[k] = lds_ld<double>(C.ta[k]);
       double acc = C.acc;
 #pragma unroll
-      for (int k = 0; k < L; ++k) acc += C.tv[k] * yt[k];
+      for (int k = 0; k < L1; ++k) acc += C.tv[k] * yt[k];
+#pragma unroll
+      for (int k = 0; k < L2; ++k) acc += C.tv[L1 + k];
       if (lane < C.nrows) {
         lds_st<double>(C.my, C.yold + (omega * (C.r - acc)) * C.invd);
         if constexpr (FWD) stream_d[C.aux] = acc;
@@ -220,24 +240,30 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const 
     PH_T(c_crit)
     bar();
     PH_T(c_bar)
-    t += 3;
-    done += 3;
+    t += kPhWaves;
+    done += kPhWaves;
   }
-  for (; done < n + 2; ++done) bar();
+  for (; done < n + kPhWaves - 1; ++done) bar();
   if (tp && w == 0 && lane == 0) { tp[0] = c_wait; tp[1] = c_p1; tp[2] = c_copy; tp[3] = c_p2; tp[4] = c_crit; tp[5] = c_bar; }
 #undef PH_T
 }
 
 template <bool FWD>
 __device__ __forceinline__ void dispatch(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
-#define PH_CASE(g, l) \
-  case (g) * 8 + (l) / 4: sweep<g, l, FWD>(R, tab, stream, stream_d, region, w, lane, omega, tp); break;
-  switch (R->G * 8 + R->L / 4) {
-    PH_CASE(0, 4) PH_CASE(0, 8) PH_CASE(0, 12) PH_CASE(0, 16) PH_CASE(0, 20) PH_CASE(0, 24) PH_CASE(0, 28)
-    PH_CASE(1, 4) PH_CASE(1, 8) PH_CASE(1, 12) PH_CASE(1, 16) PH_CASE(1, 20) PH_CASE(1, 24) PH_CASE(1, 28)
-    PH_CASE(2, 4) PH_CASE(2, 8) PH_CASE(2, 12) PH_CASE(2, 16) PH_CASE(2, 20)
-    PH_CASE(3, 4) PH_CASE(3, 8) PH_CASE(3, 12)
-    default: break;  // (the host builds no other shape; the barriers below stay matched because every wave takes this branch)
+#define PH_CASE(g, l1, l2) \
+  case (g) * 64 + ((l1) / 4) * 8 + (l2) / 8: sweep<g, l1, l2, FWD>(R, tab, stream, stream_d, region, w, lane, omega, tp); break;
+  const int l1 = (int)R->L1, l2 = R->L - l1;
+  switch (R->G * 64 + (l1 / 4) * 8 + l2 / 8) {
+    PH_CASE(0, 4, 0) PH_CASE(0, 4, 8) PH_CASE(0, 4, 16) PH_CASE(0, 4, 24) PH_CASE(0, 8, 0) PH_CASE(0, 8, 8)
+    PH_CASE(0, 8, 16) PH_CASE(0, 8, 24) PH_CASE(0, 12, 0) PH_CASE(0, 12, 8) PH_CASE(0, 12, 16) PH_CASE(0, 12, 24)
+    PH_CASE(0, 16, 0) PH_CASE(0, 16, 8) PH_CASE(0, 16, 16) PH_CASE(0, 20, 0) PH_CASE(0, 20, 8) PH_CASE(0, 20, 16)
+    PH_CASE(0, 24, 0) PH_CASE(0, 24, 8) PH_CASE(0, 28, 0) PH_CASE(0, 28, 8) PH_CASE(1, 4, 0) PH_CASE(1, 4, 8)
+    PH_CASE(1, 4, 16) PH_CASE(1, 4, 24) PH_CASE(1, 8, 0) PH_CASE(1, 8, 8) PH_CASE(1, 8, 16) PH_CASE(1, 12, 0)
+    PH_CASE(1, 12, 8) PH_CASE(1, 12, 16) PH_CASE(1, 16, 0) PH_CASE(1, 16, 8) PH_CASE(1, 20, 0) PH_CASE(1, 20, 8)
+    PH_CASE(1, 24, 0) PH_CASE(1, 28, 0) PH_CASE(2, 4, 0) PH_CASE(2, 4, 8) PH_CASE(2, 4, 16) PH_CASE(2, 8, 0)
+    PH_CASE(2, 8, 8) PH_CASE(2, 12, 0) PH_CASE(2, 12, 8) PH_CASE(2, 16, 0) PH_CASE(2, 20, 0) PH_CASE(3, 4, 0)
+    PH_CASE(3, 4, 8) PH_CASE(3, 8, 0) PH_CASE(3, 12, 0)
+    default: break;  // (the host builds no other shape; the kernel checks ph_shape_ok before anybody gets here)
   }
 #undef PH_CASE
 }
@@ -271,9 +297,9 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     }
     __syncthreads();
     if (a.prof) t1 = __builtin_amdgcn_s_memtime();
-    if (!ph_shape_ok(R.G, R.L)) {
+    if (!ph_shape_ok(R.G, (int)Rp->L1, R.L - (int)Rp->L1)) {
       // (the host builds no other shape)
-    } else if (wid < 3) {
+    } else if (wid < kPhWaves) {
       double *stream_d = reinterpret_cast<double *>(a.stream);
       const uint32_t region = ring0 + (uint32_t)wid * (uint32_t)kPhRegion;
       if (R.backward) ph::dispatch<false>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
@@ -281,13 +307,13 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     } else {
       // prefetch wave: one 4-byte copy per 128-byte line, pf_step bytes per phase, into the junk area
       const char *base = a.stream + R.stream_off;
-      const uint32_t junk = ring0 + 3u * (uint32_t)kPhRegion;
+      const uint32_t junk = ring0 + (uint32_t)kPhWaves * (uint32_t)kPhRegion;
       uint32_t cur = 0;
       const uint32_t first = min(R.pf_lead, R.stream_bytes);
       for (; cur < first; cur += 8192)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + min(cur + (uint32_t)lane * 128u, R.stream_bytes - 4u)),
                                          (__attribute__((address_space(3))) void *)(uintptr_t)junk, 4, 0, 0);
-      for (int p = 0; p < R.n_steps + 2; ++p) {
+      for (int p = 0; p < R.n_steps + kPhWaves - 1; ++p) {
         const uint32_t end = min(cur + R.pf_step, R.stream_bytes);
         for (; cur < end; cur += 8192)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + min(cur + (uint32_t)lane * 128u, R.stream_bytes - 4u)),
