@@ -80,7 +80,7 @@ struct SgsPlan {
   // three-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
   bool phased = false;
   PhRange *p_ranges = nullptr;
-  uint2 *p_blk_tab = nullptr;
+  uint4 *p_blk_tab = nullptr;
   std::vector<PhRange> host_pranges;
 };
 
@@ -143,6 +143,7 @@ struct gmg_context {
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
   bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
+  int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
   bool sgs_phase_nosplit = false;  // the whole tail is gathered in the dependent phase (comparison / tests)
   int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the three-wave sweep (value - 1: timing experiment)
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
@@ -823,7 +824,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
               const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
-              std::fprintf(stderr, "[gmg]   %s G %d L1 %2d L2 %2d steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.G, (int)P.L1, P.L - (int)P.L1, P.n_steps,
+              std::fprintf(stderr, "[gmg]   %s steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.n_steps,
                            (double)h[12 * i] / std::max(1, P.n_steps), h[12 * i + 2] + h[12 * i + 3], h[12 * i + 4] / turns, h[12 * i + 5] / turns, h[12 * i + 6] / turns, h[12 * i + 7] / turns,
                            h[12 * i + 8] / turns, h[12 * i + 9] / turns);
             }
@@ -1201,7 +1202,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : y_max;
   y_cap = std::max(64, std::min(y_cap, y_max)) & ~1;
   std::vector<PhRange> pranges;
-  std::vector<uint2> blk_tab;
+  std::vector<uint4> blk_tab;
+  std::vector<int64_t> hist_l1(8, 0), hist_l2(4, 0), hist_g(4, 0);  // shapes of the steps (debug print)
   std::vector<int32_t> row_ci((size_t)n, -1), ci_row, rpos_f, rpos_b, ws_ci, block_rng((size_t)n_blocks + 1, 0);
   std::vector<double> iso_diag((size_t)n, 0.0), iso_invd((size_t)n, 1.0);
   std::vector<SwRange> ranges;
@@ -1407,39 +1409,69 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               if (first_late < 0) { first_late = ne; last_late = ne - 1; }
               cut.push_back(RowCut{ne, first_late, last_late});
             }
-          // shape: head (8 G) | T1 (L1: from the first late column to the last, gathered in the dependent phase) | T2 (L2: behind
-          // the last late column, products formed ahead).  A row may give the end of its head and the start of its T2 to T1;
-          // of the shapes every row of the range fits, the one with the cheapest phase (measured costs, cycles) is taken.
+          // shape of a step: head (8 G) | T1 (L1: from the first late column to the last, gathered in the dependent phase) | T2 (L2:
+          // behind the last late column, products formed ahead).  A row may give the end of its head and the start of its T2 to
+          // T1; of the shapes every row of the step fits, the one with the cheapest phase (measured costs, cycles) is taken.
           auto fits = [&](const RowCut &rc, int g, int l1, int l2, int *h0o, int *h1o) {
             const int h1 = std::max(rc.last + 1, rc.ne - l2), h0 = std::max(std::min(rc.first, 8 * g), h1 - l1);
             if (h0 > rc.first || h0 > 8 * g || h0 < 0) return false;
             if (h0o) { *h0o = h0; *h1o = h1; }
             return true;
           };
-          int Gr = -1, L1r = 0, L2r = 0;
+          struct Shape { int g, l1, l2; };
+          std::vector<Shape> shape_of;
           {
-            const double avg_rows = (double)cut.size() / (double)(s1 - s0);
-            double best = 1e300;
-            for (int g = 0; g <= 3; ++g)
-              for (int l1 = 4; l1 <= 28; l1 += 4)
-                for (int l2 = 0; l2 <= 24; l2 += 8) {
-                  if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
-                  bool ok = true;
-                  for (const RowCut &rc : cut)
-                    if (!fits(rc, g, l1, l2, nullptr, nullptr)) { ok = false; break; }
-                  if (!ok) continue;
-                  const int ent = 8 * g + l1 + l2;
-                  const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + avg_rows * ph_stride(g, l1 + l2)) / 1024.0,
-                               p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
-                  const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
-                  if (cost < best) { best = cost; Gr = g; L1r = l1; L2r = l2; }
-                }
+            size_t c0 = 0;
+            for (size_t st = s0; st < s1; ++st) {
+              const int nr = steps[st].nrows;
+              double best = 1e300;
+              Shape bs{-1, 0, 0};
+              for (int g = 0; g <= 3; ++g)
+                for (int l1 = 4; l1 <= 28; l1 += 4)
+                  for (int l2 = 0; l2 <= 24; l2 += 8) {
+                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
+                    bool ok = true;
+                    for (int u = 0; u < nr && ok; ++u) ok = fits(cut[c0 + (size_t)u], g, l1, l2, nullptr, nullptr);
+                    if (!ok) continue;
+                    const int ent = 8 * g + l1 + l2;
+                    const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + (double)nr * ph_stride(g, l1 + l2)) / 1024.0,
+                                 p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
+                    const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
+                  }
+              if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+              shape_of.push_back(bs);
+              c0 += (size_t)nr;
+            }
+            // A wave pays ~400 cycles when its next step has another shape (another stretch of code): the steps are taken
+            // in chunks, one shape per chunk -- the cheapest that holds every row of the chunk.
+            const int chunk = ctx->sgs_phase_chunk > 0 ? ctx->sgs_phase_chunk : 32;
+            std::vector<size_t> cpos(shape_of.size() + 1, 0);
+            for (size_t q = 0; q < shape_of.size(); ++q) cpos[q + 1] = cpos[q] + (size_t)steps[s0 + q].nrows;
+            for (size_t q0 = 0; q0 < shape_of.size(); q0 += (size_t)chunk) {
+              const size_t q1 = std::min(shape_of.size(), q0 + (size_t)chunk);
+              double best = 1e300;
+              Shape bs{-1, 0, 0};
+              const double avg_rows = (double)(cpos[q1] - cpos[q0]) / (double)(q1 - q0);
+              for (int g = 0; g <= 3; ++g)
+                for (int l1 = 4; l1 <= 28; l1 += 4)
+                  for (int l2 = 0; l2 <= 24; l2 += 8) {
+                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
+                    bool ok = true;
+                    for (size_t u = cpos[q0]; u < cpos[q1] && ok; ++u) ok = fits(cut[u], g, l1, l2, nullptr, nullptr);
+                    if (!ok) continue;
+                    const int ent = 8 * g + l1 + l2;
+                    const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + avg_rows * ph_stride(g, l1 + l2)) / 1024.0,
+                                 p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
+                    const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
+                  }
+              if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
+              for (size_t q = q0; q < q1; ++q) shape_of[q] = bs;
+            }
           }
-          if (Gr < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
-          const int Lr = L1r + L2r;
-          const int pstride = ph_stride(Gr, Lr);
           PhRange P{};
-          P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir; P.G = Gr; P.L = Lr; P.L1 = (uint32_t)L1r;
+          P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir;
           P.n_steps = (int32_t)(s1 - s0);
           const int64_t base = ((int64_t)stream.size() + 1023) / 1024 * 1024;
           P.stream_off = base;
@@ -1448,6 +1480,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           size_t tix = 0;
           for (size_t st = s0; st < s1; ++st) {
             const Step &S = steps[st];
+            const Shape sh = shape_of[st - s0];
+            const int Gr = sh.g, L1r = sh.l1, Lr = sh.l1 + sh.l2, pstride = ph_stride(Gr, Lr);
             const int64_t raw = 16 + (int64_t)S.nrows * pstride;
             boff.push_back(off); bbytes.push_back(raw);
             stream.resize((size_t)(base + off + raw), 0);
@@ -1471,10 +1505,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               for (int e = 0; e < 8 * Gr; ++e) { hv[e] = 0.0; ha[e] = my; }
               for (int e = 0; e < Lr; ++e) { tv[e] = 0.0; ta[e] = my; }
               const RowCut &rc = cut[tix];
-              const int ne = rc.ne;
               // head [0, h0), T1 [h0, h1), T2 [h1, ne)
-              int h0 = 0, h1 = ne;
-              (void)fits(rc, Gr, L1r, L2r, &h0, &h1);
+              int h0 = 0, h1 = rc.ne;
+              (void)fits(rc, Gr, L1r, sh.l2, &h0, &h1);
               int e = 0;
               for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
                 const int c = pcol[(size_t)k];
@@ -1491,16 +1524,21 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           }
           P.blk_tab = (uint32_t)blk_tab.size();
           for (size_t q = 0; q < boff.size(); ++q) {
-            blk_tab.push_back(uint2{(uint32_t)boff[q], (uint32_t)bbytes[q]});
+            const Shape sh = shape_of[q];
+            blk_tab.push_back(uint4{(uint32_t)boff[q], (uint32_t)bbytes[q], (uint32_t)ph::ph_key(sh.g, sh.l1, sh.l2), 0u});
             uint32_t *h = reinterpret_cast<uint32_t *>(stream.data() + base + boff[q]);
-            if (q + kPhWaves < boff.size()) { h[1] = (uint32_t)bbytes[q + kPhWaves]; h[2] = (uint32_t)boff[q + kPhWaves]; }  // the block its reader copies next
+            if (q + kPhWaves < boff.size()) {  // the block its reader copies next, and that step's shape
+              const Shape nx = shape_of[q + kPhWaves];
+              h[1] = (uint32_t)bbytes[q + kPhWaves]; h[2] = (uint32_t)boff[q + kPhWaves]; h[3] = (uint32_t)ph::ph_key(nx.g, nx.l1, nx.l2);
+            }
+            hist_l1[(size_t)std::min(7, sh.l1 / 4)]++; hist_l2[(size_t)(sh.l2 / 8)]++; hist_g[(size_t)sh.g]++;
           }
           const int64_t padded = (off + 2048 + 1023) / 1024 * 1024;  // the copies read whole KB: up to 1008 bytes beyond a block
           if (padded >= ((int64_t)1 << 31) || (base + padded) / 8 >= ((int64_t)1 << 31)) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
           stream.resize((size_t)(base + padded), 0);
           P.stream_bytes = (uint32_t)padded;
           // prefetch wave: pf_step bytes per phase starting pf_lead bytes ahead, never behind block p + 12 at phase p
-          const int64_t nph = P.n_steps + 2;
+          const int64_t nph = P.n_steps + kPhWaves - 1;
           const int64_t step_b = ((off + nph - 1) / nph + 127) / 128 * 128;
           int64_t lead = 65536;
           for (int64_t q = 0; q < (int64_t)boff.size(); ++q) {
@@ -1593,7 +1631,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
   SW_UP(G.w_ranges, ranges, SwRange)
   SW_UP(G.p_ranges, pranges, PhRange)
-  SW_UP(G.p_blk_tab, blk_tab, uint2)
+  SW_UP(G.p_blk_tab, blk_tab, uint4)
   SW_UP(G.w_block_rng, block_rng, int32_t)
   SW_UP(G.w_ws_ci, ws_ci, int32_t)
   SW_UP(G.w_ci_row, ci_row, int32_t)
@@ -1632,6 +1670,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   hipFuncAttributes fa{};
   HIPC(hipFuncGetAttributes(&fa, ph ? (const void *)sgs_phase_kernel : (const void *)sgs_wave_kernel<false>));
   G.wave = fa.sharedSizeBytes == 0;
+  if (ctx->debug_upload && ph)
+    std::fprintf(stderr, "[gmg] SGS step shapes: G %lld %lld %lld %lld | L1/4 %lld %lld %lld %lld %lld %lld %lld %lld | L2/8 %lld %lld %lld %lld\n", (long long)hist_g[0], (long long)hist_g[1],
+                 (long long)hist_g[2], (long long)hist_g[3], (long long)hist_l1[0], (long long)hist_l1[1], (long long)hist_l1[2], (long long)hist_l1[3], (long long)hist_l1[4],
+                 (long long)hist_l1[5], (long long)hist_l1[6], (long long)hist_l1[7], (long long)hist_l2[0], (long long)hist_l2[1], (long long)hist_l2[2], (long long)hist_l2[3]);
   if (ctx->debug_upload)
     std::fprintf(stderr, "[gmg] SGS %s plan: %lld rows, %lld coupled, %d blocks, %lld stages, %lld sub-steps, %d ranges, y slots %d, stream %.1f MB\n",
                  ph ? "three-wave" : "wave", (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
@@ -2399,6 +2441,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
   else if (k == "sgs_phase_profile") ctx->sgs_phase_profile = (int)value;
   else if (k == "sgs_phase_nosplit") ctx->sgs_phase_nosplit = on;
+  else if (k == "sgs_phase_chunk") ctx->sgs_phase_chunk = (int)value;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
   else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }

@@ -44,7 +44,7 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 }
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.  A step's block: 16-byte
-// header {nrows, bytes of the block three steps on (0: none), its offset in the range's stream, -}, then one record
+// header {nrows, bytes of the block four steps on (0: none), its offset in the range's stream, its shape key}, then one record
 // per row:  +0 r  +8 1/a_ii  +16 prefix (backward: the forward sweep's sum)  +24 u32 LDS address of the row's y
 //           +28 u32 aux (forward: index, in doubles, of the prefix field of the row's backward record)
 //           +32 head values [8 G]   tail values [L]   head LDS addresses u32 [8 G]   tail LDS addresses u32 [L]
@@ -62,7 +62,7 @@ struct SgsPhaseArgs {
   const int32_t *block_rng;
   int block0;
   char *stream;
-  const uint2 *blk_tab;      // per step {offset in its range's stream, bytes}
+  const uint4 *blk_tab;      // per step {offset in its range's stream, bytes, shape key, -}
   const int32_t *ws_ci, *ci_row;
   double *ycur, *y;
   double omega;
@@ -134,138 +134,159 @@ struct Rec {
   int nrows;
 };
 
+// what a wave carries from one of its steps to the next
+struct Turn {
+  uint32_t nx_off, nx_bytes;  // its next block in the range's stream (bytes 0: none)
+  int key;                    // shape of its next step
+  unsigned long long c_wait, c_p1, c_copy, c_p2, c_crit, c_bar, m0;
+};
+__host__ __device__ constexpr int ph_key(int g, int l1, int l2) { return g * 64 + (l1 / 4) * 8 + l2 / 8; }
+
+// One step of shape (G, L1, L2) by one wave: four phases, four barriers.
 template <int G, int L1, int L2, bool FWD>
-__device__ __forceinline__ void sweep(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
+__device__ __forceinline__ void turn(Turn &T, bool first, const char *base, double *stream_d, uint32_t region, int lane, double omega, bool timed) {
   constexpr int L = L1 + L2;
   constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
-  const int n = R->n_steps;
-  const char *base = stream + R->stream_off;
   Rec<G, L> C;
-  int t = w;
-  if (t < n) { const uint2 e = tab[t]; copy_to_lds(base + e.x, region, e.y, lane); }
-  for (int i = 0; i < w; ++i) bar();
-  int done = w;
-  uint2 nxt{0u, 0u};
-  unsigned long long c_wait = 0, c_p1 = 0, c_copy = 0, c_p2 = 0, c_crit = 0, c_bar = 0, m0 = 0, m1 = 0;
-#define PH_T(acc) if (tp) { m1 = __builtin_amdgcn_s_memtime(); acc += m1 - m0; m0 = m1; }
-  if (tp) m0 = __builtin_amdgcn_s_memtime();
-  while (t < n) {
-    // ---- P1: records -> registers
-    if (FWD && t != w) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): my block has arrived; the prefix store of my last step may be on its way
-    else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
-    PH_T(c_wait)
-    {
-      const u32x4 hdr = lds_ld<u32x4>(region);
-      C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
-      nxt.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); nxt.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
-      const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
-      const f64x2 ri = lds_ld<f64x2>(rec);
-      const u32x4 q = lds_ld<u32x4>(rec + 16);
-      C.r = ri.x; C.invd = ri.y;
-      C.prefix = __hiloint2double((int)q.y, (int)q.x);
-      C.my = q.z; C.aux = q.w;
+  unsigned long long m1 = 0;
+#define PH_T(acc) if (timed) { m1 = __builtin_amdgcn_s_memtime(); T.acc += m1 - T.m0; T.m0 = m1; }
+  // ---- P1: records -> registers
+  if (FWD && !first) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): my block has arrived; the prefix store of my last step may be on its way
+  else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
+  PH_T(c_wait)
+  {
+    const u32x4 hdr = lds_ld<u32x4>(region);
+    C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
+    T.nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); T.nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
+    T.key = __builtin_amdgcn_readfirstlane((int)hdr.w);
+    const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
+    const f64x2 ri = lds_ld<f64x2>(rec);
+    const u32x4 q = lds_ld<u32x4>(rec + 16);
+    C.r = ri.x; C.invd = ri.y;
+    C.prefix = __hiloint2double((int)q.y, (int)q.x);
+    C.my = q.z; C.aux = q.w;
 #pragma unroll
-      for (int j = 0; j < 4 * G; ++j) {
-        const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
-        C.hv[2 * j] = a2.x; C.hv[2 * j + 1] = a2.y;
-      }
-#pragma unroll
-      for (int j = 0; j < L / 2; ++j) {
-        const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 64 * G + 16 * j);
-        C.tv[2 * j] = a2.x; C.tv[2 * j + 1] = a2.y;
-      }
-#pragma unroll
-      for (int j = 0; j < 2 * G; ++j) {
-        const u32x4 c = lds_ld<u32x4>(rec + 32 + 64 * G + 8 * L + 16 * j);
-        C.ha[4 * j] = c.x; C.ha[4 * j + 1] = c.y; C.ha[4 * j + 2] = c.z; C.ha[4 * j + 3] = c.w;
-      }
-#pragma unroll
-      for (int j = 0; j < L / 4; ++j) {
-        const u32x4 c = lds_ld<u32x4>(rec + 32 + 96 * G + 8 * L + 16 * j);
-        C.ta[4 * j] = c.x; C.ta[4 * j + 1] = c.y; C.ta[4 * j + 2] = c.z; C.ta[4 * j + 3] = c.w;
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the region is done: it may be overwritten
-      PH_T(c_p1)
+    for (int j = 0; j < 4 * G; ++j) {
+      const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 16 * j);
+      C.hv[2 * j] = a2.x; C.hv[2 * j + 1] = a2.y;
     }
-    bar();
-    PH_T(c_bar)
-    // ---- COPY: my next block (step t + 4) global -> LDS; it is read three phases on
-    if (nxt.y) copy_to_lds(base + nxt.x, region, nxt.y, lane);
-    PH_T(c_copy)
-    bar();
-    PH_T(c_bar)
-    // ---- P2: the head
-    // (no column of the head is written in this phase or the next)
-    {
-      double yh[G > 0 ? 8 * G : 1];
 #pragma unroll
-      for (int k = 0; k < 8 * G; ++k) yh[k] = lds_ld<double>(C.ha[k]);
-      C.yold = 0.0;
-      if constexpr (!FWD) C.yold = lds_ld<double>(C.my);
-      double acc = FWD ? 0.0 : C.prefix;
-#pragma unroll
-      for (int k = 0; k < 8 * G; ++k) acc += C.hv[k] * yh[k];
-      asm volatile("" : "+v"(acc));  // formed here, not after the barrier (the compiler would sink the chain into CRIT)
-      C.acc = acc;
-      // the tail behind the last late column: its products are formed here, CRIT only adds them
-      double y2[L2 > 0 ? L2 : 1];
-#pragma unroll
-      for (int k = 0; k < L2; ++k) y2[k] = lds_ld<double>(C.ta[L1 + k]);
-#pragma unroll
-      for (int k = 0; k < L2; ++k) {
-        double pr = C.tv[L1 + k] * y2[k];
-        asm volatile("" : "+v"(pr));
-        C.tv[L1 + k] = pr;
-      }
+    for (int j = 0; j < L / 2; ++j) {
+      const f64x2 a2 = lds_ld<f64x2>(rec + 32 + 64 * G + 16 * j);
+      C.tv[2 * j] = a2.x; C.tv[2 * j + 1] = a2.y;
     }
-    PH_T(c_p2)
-    bar();
-    PH_T(c_bar)
-    // ---- CRIT: the tail
-    {
-      double yt[L1];
 #pragma unroll
-      for (int k = 0; k < L1; ++k) yt[k] = lds_ld<double>(C.ta[k]);
-      double acc = C.acc;
-#pragma unroll
-      for (int k = 0; k < L1; ++k) acc += C.tv[k] * yt[k];
-#pragma unroll
-      for (int k = 0; k < L2; ++k) acc += C.tv[L1 + k];
-      if (lane < C.nrows) {
-        lds_st<double>(C.my, C.yold + (omega * (C.r - acc)) * C.invd);
-        if constexpr (FWD) stream_d[C.aux] = acc;
-      }
+    for (int j = 0; j < 2 * G; ++j) {
+      const u32x4 c = lds_ld<u32x4>(rec + 32 + 64 * G + 8 * L + 16 * j);
+      C.ha[4 * j] = c.x; C.ha[4 * j + 1] = c.y; C.ha[4 * j + 2] = c.z; C.ha[4 * j + 3] = c.w;
     }
-    if (tp) { __builtin_amdgcn_s_waitcnt(0xc07f); }
-    PH_T(c_crit)
-    bar();
-    PH_T(c_bar)
-    t += kPhWaves;
-    done += kPhWaves;
+#pragma unroll
+    for (int j = 0; j < L / 4; ++j) {
+      const u32x4 c = lds_ld<u32x4>(rec + 32 + 96 * G + 8 * L + 16 * j);
+      C.ta[4 * j] = c.x; C.ta[4 * j + 1] = c.y; C.ta[4 * j + 2] = c.z; C.ta[4 * j + 3] = c.w;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the region is done: it may be overwritten
+    PH_T(c_p1)
   }
-  for (; done < n + kPhWaves - 1; ++done) bar();
-  if (tp && w == 0 && lane == 0) { tp[0] = c_wait; tp[1] = c_p1; tp[2] = c_copy; tp[3] = c_p2; tp[4] = c_crit; tp[5] = c_bar; }
+  bar();
+  PH_T(c_bar)
+  // ---- COPY: my next block (step t + 4) global -> LDS; it is read three phases on
+  if (T.nx_bytes) copy_to_lds(base + T.nx_off, region, T.nx_bytes, lane);
+  PH_T(c_copy)
+  bar();
+  PH_T(c_bar)
+  // ---- P2: the head (no column of it is written in this phase or the next) and the products behind the last late column
+  {
+    double yh[G > 0 ? 8 * G : 1];
+#pragma unroll
+    for (int k = 0; k < 8 * G; ++k) yh[k] = lds_ld<double>(C.ha[k]);
+    C.yold = 0.0;
+    if constexpr (!FWD) C.yold = lds_ld<double>(C.my);
+    double y2[L2 > 0 ? L2 : 1];
+#pragma unroll
+    for (int k = 0; k < L2; ++k) y2[k] = lds_ld<double>(C.ta[L1 + k]);
+    double acc = FWD ? 0.0 : C.prefix;
+#pragma unroll
+    for (int k = 0; k < 8 * G; ++k) acc += C.hv[k] * yh[k];
+    asm volatile("" : "+v"(acc));  // formed here, not after the barrier (the compiler would sink the chain into CRIT)
+    C.acc = acc;
+#pragma unroll
+    for (int k = 0; k < L2; ++k) {
+      double pr = C.tv[L1 + k] * y2[k];
+      asm volatile("" : "+v"(pr));
+      C.tv[L1 + k] = pr;
+    }
+  }
+  PH_T(c_p2)
+  bar();
+  PH_T(c_bar)
+  // ---- CRIT: from the first late column on
+  {
+    double yt[L1];
+#pragma unroll
+    for (int k = 0; k < L1; ++k) yt[k] = lds_ld<double>(C.ta[k]);
+    double acc = C.acc;
+#pragma unroll
+    for (int k = 0; k < L1; ++k) acc += C.tv[k] * yt[k];
+#pragma unroll
+    for (int k = 0; k < L2; ++k) acc += C.tv[L1 + k];
+    if (lane < C.nrows) {
+      lds_st<double>(C.my, C.yold + (omega * (C.r - acc)) * C.invd);
+      if constexpr (FWD) stream_d[C.aux] = acc;
+    }
+  }
+  if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); }
+  PH_T(c_crit)
+  bar();
+  PH_T(c_bar)
 #undef PH_T
 }
 
+// The steps t = w, w + 4, ... of a range by compute wave w.  Every step has its own shape (its key travels in the header
+// of the wave's previous block): one indirect branch per turn, in the phase that only reads records.
 template <bool FWD>
-__device__ __forceinline__ void dispatch(const PhRange *R, const uint2 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega, unsigned long long *tp) {
-#define PH_CASE(g, l1, l2) \
-  case (g) * 64 + ((l1) / 4) * 8 + (l2) / 8: sweep<g, l1, l2, FWD>(R, tab, stream, stream_d, region, w, lane, omega, tp); break;
-  const int l1 = (int)R->L1, l2 = R->L - l1;
-  switch (R->G * 64 + (l1 / 4) * 8 + l2 / 8) {
-    PH_CASE(0, 4, 0) PH_CASE(0, 4, 8) PH_CASE(0, 4, 16) PH_CASE(0, 4, 24) PH_CASE(0, 8, 0) PH_CASE(0, 8, 8)
-    PH_CASE(0, 8, 16) PH_CASE(0, 8, 24) PH_CASE(0, 12, 0) PH_CASE(0, 12, 8) PH_CASE(0, 12, 16) PH_CASE(0, 12, 24)
-    PH_CASE(0, 16, 0) PH_CASE(0, 16, 8) PH_CASE(0, 16, 16) PH_CASE(0, 20, 0) PH_CASE(0, 20, 8) PH_CASE(0, 20, 16)
-    PH_CASE(0, 24, 0) PH_CASE(0, 24, 8) PH_CASE(0, 28, 0) PH_CASE(0, 28, 8) PH_CASE(1, 4, 0) PH_CASE(1, 4, 8)
-    PH_CASE(1, 4, 16) PH_CASE(1, 4, 24) PH_CASE(1, 8, 0) PH_CASE(1, 8, 8) PH_CASE(1, 8, 16) PH_CASE(1, 12, 0)
-    PH_CASE(1, 12, 8) PH_CASE(1, 12, 16) PH_CASE(1, 16, 0) PH_CASE(1, 16, 8) PH_CASE(1, 20, 0) PH_CASE(1, 20, 8)
-    PH_CASE(1, 24, 0) PH_CASE(1, 28, 0) PH_CASE(2, 4, 0) PH_CASE(2, 4, 8) PH_CASE(2, 4, 16) PH_CASE(2, 8, 0)
-    PH_CASE(2, 8, 8) PH_CASE(2, 12, 0) PH_CASE(2, 12, 8) PH_CASE(2, 16, 0) PH_CASE(2, 20, 0) PH_CASE(3, 4, 0)
-    PH_CASE(3, 4, 8) PH_CASE(3, 8, 0) PH_CASE(3, 12, 0)
-    default: break;  // (the host builds no other shape; the kernel checks ph_shape_ok before anybody gets here)
+__device__ __forceinline__ void sweep(const PhRange *R, const uint4 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega,
+                                      unsigned long long *tp) {
+  const int n = R->n_steps;
+  const char *base = stream + R->stream_off;
+  Turn T{};
+  int t = w;
+  if (t < n) {
+    const uint4 e = tab[t];
+    T.key = (int)e.z;
+    copy_to_lds(base + e.x, region, e.y, lane);
   }
+  for (int i = 0; i < w; ++i) bar();
+  int done = w;
+  const bool timed = tp != nullptr;
+  if (timed) T.m0 = __builtin_amdgcn_s_memtime();
+  while (t < n) {
+#define PH_CASE(g, l1, l2) \
+    case ph_key(g, l1, l2): \
+      do { \
+        turn<g, l1, l2, FWD>(T, t == w, base, stream_d, region, lane, omega, timed); \
+        t += kPhWaves; done += kPhWaves; \
+      } while (t < n && T.key == ph_key(g, l1, l2));  /* (steps of one shape in a row: no dispatch in between) */ \
+      break;
+    switch (T.key) {
+      PH_CASE(0, 4, 0) PH_CASE(0, 4, 8) PH_CASE(0, 4, 16) PH_CASE(0, 4, 24) PH_CASE(0, 8, 0) PH_CASE(0, 8, 8)
+      PH_CASE(0, 8, 16) PH_CASE(0, 8, 24) PH_CASE(0, 12, 0) PH_CASE(0, 12, 8) PH_CASE(0, 12, 16) PH_CASE(0, 12, 24)
+      PH_CASE(0, 16, 0) PH_CASE(0, 16, 8) PH_CASE(0, 16, 16) PH_CASE(0, 20, 0) PH_CASE(0, 20, 8) PH_CASE(0, 20, 16)
+      PH_CASE(0, 24, 0) PH_CASE(0, 24, 8) PH_CASE(0, 28, 0) PH_CASE(0, 28, 8) PH_CASE(1, 4, 0) PH_CASE(1, 4, 8)
+      PH_CASE(1, 4, 16) PH_CASE(1, 4, 24) PH_CASE(1, 8, 0) PH_CASE(1, 8, 8) PH_CASE(1, 8, 16) PH_CASE(1, 12, 0)
+      PH_CASE(1, 12, 8) PH_CASE(1, 12, 16) PH_CASE(1, 16, 0) PH_CASE(1, 16, 8) PH_CASE(1, 20, 0) PH_CASE(1, 20, 8)
+      PH_CASE(1, 24, 0) PH_CASE(1, 28, 0) PH_CASE(2, 4, 0) PH_CASE(2, 4, 8) PH_CASE(2, 4, 16) PH_CASE(2, 8, 0)
+      PH_CASE(2, 8, 8) PH_CASE(2, 12, 0) PH_CASE(2, 12, 8) PH_CASE(2, 16, 0) PH_CASE(2, 20, 0) PH_CASE(3, 4, 0)
+      PH_CASE(3, 4, 8) PH_CASE(3, 8, 0) PH_CASE(3, 12, 0)
+      default:  // (the host builds no other shape)
+        for (int i = 0; i < kPhWaves; ++i) bar();
+        t += kPhWaves; done += kPhWaves;
+        break;
+    }
 #undef PH_CASE
+  }
+  for (; done < n + kPhWaves - 1; ++done) bar();
+  if (tp && w == 0 && lane == 0) { tp[0] = T.c_wait; tp[1] = T.c_p1; tp[2] = T.c_copy; tp[3] = T.c_p2; tp[4] = T.c_crit; tp[5] = T.c_bar; }
 }
 
 }  // namespace ph
@@ -297,13 +318,11 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     }
     __syncthreads();
     if (a.prof) t1 = __builtin_amdgcn_s_memtime();
-    if (!ph_shape_ok(R.G, (int)Rp->L1, R.L - (int)Rp->L1)) {
-      // (the host builds no other shape)
-    } else if (wid < kPhWaves) {
+    if (wid < kPhWaves) {
       double *stream_d = reinterpret_cast<double *>(a.stream);
       const uint32_t region = ring0 + (uint32_t)wid * (uint32_t)kPhRegion;
-      if (R.backward) ph::dispatch<false>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
-      else ph::dispatch<true>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
+      if (R.backward) ph::sweep<false>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
+      else ph::sweep<true>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
     } else {
       // prefetch wave: one 4-byte copy per 128-byte line, pf_step bytes per phase, into the junk area
       const char *base = a.stream + R.stream_off;
