@@ -144,6 +144,7 @@ struct gmg_context {
   bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
   int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
+  bool sgs_phase_nocascade = false;  // every step gathers all T1 slots of its shape (comparison)
   bool sgs_phase_nosplit = false;  // the whole tail is gathered in the dependent phase (comparison / tests)
   int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the three-wave sweep (value - 1: timing experiment)
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
@@ -1486,7 +1487,14 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             boff.push_back(off); bbytes.push_back(raw);
             stream.resize((size_t)(base + off + raw), 0);
             char *blk = stream.data() + base + off;
-            reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)S.nrows;
+            int t1_used = 0;
+            for (int u = 0; u < S.nrows; ++u) {
+              int h0 = 0, h1 = 0;
+              (void)fits(cut[tix + (size_t)u], Gr, L1r, sh.l2, &h0, &h1);
+              t1_used = std::max(t1_used, h1 - h0);
+            }
+            t1_used = ctx->sgs_phase_nocascade ? L1r : std::min(L1r, std::max(4, (t1_used + 3) / 4 * 4));
+            reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)S.nrows | ((uint32_t)t1_used << 16);
             for (int u = 0; u < S.nrows; ++u) {
               const int i = seq[(size_t)(S.first + u)];
               const int32_t ci = row_ci[(size_t)(rb + i)];
@@ -2441,6 +2449,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
   else if (k == "sgs_phase_profile") ctx->sgs_phase_profile = (int)value;
   else if (k == "sgs_phase_nosplit") ctx->sgs_phase_nosplit = on;
+  else if (k == "sgs_phase_nocascade") ctx->sgs_phase_nocascade = on;
   else if (k == "sgs_phase_chunk") ctx->sgs_phase_chunk = (int)value;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;

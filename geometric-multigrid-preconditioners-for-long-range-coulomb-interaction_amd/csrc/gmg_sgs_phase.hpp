@@ -44,7 +44,7 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 }
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.  A step's block: 16-byte
-// header {nrows, bytes of the block four steps on (0: none), its offset in the range's stream, its shape key}, then one record
+// header {nrows | T1 slots in use << 16, bytes of the block four steps on (0: none), its offset in the range's stream, its shape key}, then one record
 // per row:  +0 r  +8 1/a_ii  +16 prefix (backward: the forward sweep's sum)  +24 u32 LDS address of the row's y
 //           +28 u32 aux (forward: index, in doubles, of the prefix field of the row's backward record)
 //           +32 head values [8 G]   tail values [L]   head LDS addresses u32 [8 G]   tail LDS addresses u32 [L]
@@ -148,6 +148,7 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
   constexpr int L = L1 + L2;
   constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
   Rec<G, L> C;
+  int l1s = L1;  // T1 slots this step really uses (multiple of 4): the dependent phase stops there
   unsigned long long m1 = 0;
 #define PH_T(acc) if (timed) { m1 = __builtin_amdgcn_s_memtime(); T.acc += m1 - T.m0; T.m0 = m1; }
   // ---- P1: records -> registers
@@ -156,7 +157,9 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
   PH_T(c_wait)
   {
     const u32x4 hdr = lds_ld<u32x4>(region);
-    C.nrows = __builtin_amdgcn_readfirstlane((int)hdr.x);
+    const int h0 = __builtin_amdgcn_readfirstlane((int)hdr.x);
+    C.nrows = h0 & 0xffff;
+    l1s = h0 >> 16;
     T.nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); T.nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
     T.key = __builtin_amdgcn_readfirstlane((int)hdr.w);
     const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
@@ -222,12 +225,21 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
   PH_T(c_bar)
   // ---- CRIT: from the first late column on
   {
+    // (in pieces of four, left by one forward branch: the shape is the chunk's, most steps need fewer slots)
     double yt[L1];
 #pragma unroll
-    for (int k = 0; k < L1; ++k) yt[k] = lds_ld<double>(C.ta[k]);
+    for (int q = 0; q < L1 / 4; ++q) {
+      if (q > 0 && 4 * q >= l1s) break;
+#pragma unroll
+      for (int k = 4 * q; k < 4 * q + 4; ++k) yt[k] = lds_ld<double>(C.ta[k]);
+    }
     double acc = C.acc;
 #pragma unroll
-    for (int k = 0; k < L1; ++k) acc += C.tv[k] * yt[k];
+    for (int q = 0; q < L1 / 4; ++q) {
+      if (q > 0 && 4 * q >= l1s) break;
+#pragma unroll
+      for (int k = 4 * q; k < 4 * q + 4; ++k) acc += C.tv[k] * yt[k];
+    }
 #pragma unroll
     for (int k = 0; k < L2; ++k) acc += C.tv[L1 + k];
     if (lane < C.nrows) {
@@ -305,15 +317,15 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     const int32_t *ws = a.ws_ci + R.ws_off;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (a.prof) t0 = __builtin_amdgcn_s_memtime();
-    for (int k0 = tid; k0 < R.n_ws; k0 += 8 * kPhThreads) {  // eight independent gathers in flight per thread
-      int ci[8];
-      double v[8];
+    for (int k0 = tid; k0 < R.n_ws; k0 += 16 * kPhThreads) {  // sixteen independent gathers in flight per thread
+      int ci[16];
+      double v[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ci[j] = k0 + j * kPhThreads < R.n_ws ? ws[k0 + j * kPhThreads] : -1;
+      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_ws ? ws[k0 + j * kPhThreads] : -1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = ci[j] >= 0 ? a.ycur[ci[j]] : 0.0;
+      for (int j = 0; j < 16; ++j) v[j] = ci[j] >= 0 ? a.ycur[ci[j]] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < 16; ++j)
         if (ci[j] >= 0) ylds[k0 + j * kPhThreads] = v[j];
     }
     __syncthreads();
@@ -343,14 +355,14 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): prefix stores, leftover copies
     __syncthreads();
     if (a.prof) t2 = __builtin_amdgcn_s_memtime();
-    for (int k0 = tid; k0 < R.n_own; k0 += 8 * kPhThreads) {
-      int ci[8], row[8];
+    for (int k0 = tid; k0 < R.n_own; k0 += 16 * kPhThreads) {
+      int ci[16], row[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? ws[k0 + j * kPhThreads] : -1;
+      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? ws[k0 + j * kPhThreads] : -1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) row[j] = (R.backward && ci[j] >= 0) ? a.ci_row[ci[j]] : -1;
+      for (int j = 0; j < 16; ++j) row[j] = (R.backward && ci[j] >= 0) ? a.ci_row[ci[j]] : -1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < 16; ++j)
         if (ci[j] >= 0) {
           const double v = ylds[k0 + j * kPhThreads];
           a.ycur[ci[j]] = v;
