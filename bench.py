@@ -199,7 +199,7 @@ def main():
             if st_.sgs_samples:
                 e["sweep_launches_per_solve"] = round(st_.sgs_samples / steps_, 1)
                 e["sweep_ms_per_solve"] = round(st_.sgs_ms_total / steps_, 3)
-                e["sweep_ns_per_dependent_substep"] = round(st_.sgs_ms_total * 1e6 / max(1, st_.sgs_substeps) * (blocks if blocks > 1 else 1), 1)
+                e["sweep_ns_per_dependent_step"] = round(st_.sgs_ms_total * 1e6 / max(1, st_.sgs_substeps) * (blocks if blocks > 1 else 1), 1)
         return e
 
     head_key = f"SSOR_B{args.ssor_blocks}" if args.smoother == "SSOR" else args.smoother
@@ -270,9 +270,10 @@ def main():
             roof["kernel_time_per_step"] = {
                 "level0_spmv_ms": round(t_k * 1e3 * st.coarse_iterations / args.steps, 3),
                 "ssor_sweep_ms": round(st.sgs_ms_total / args.steps, 3),
-                "ssor_sweep_note": "sgs_wave_kernel is a chain of dependent sub-steps (one wave, y in LDS): latency bound, "
-                                   "no bandwidth roofline applies; its figure of merit is ns per dependent sub-step",
-                "ssor_sweep_ns_per_dependent_substep": smoothers[head_key].get("sweep_ns_per_dependent_substep"),
+                "ssor_sweep_note": "sgs_phase_kernel is a chain of dependent steps (<= 32 rows of one dependency stage each, taken in turn "
+                                   "by four waves of one workgroup, y in LDS): latency bound, no bandwidth roofline applies; its figure "
+                                   "of merit is ns per dependent step",
+                "ssor_sweep_ns_per_dependent_step": smoothers[head_key].get("sweep_ns_per_dependent_step"),
                 "ssor_sweep_stream_GBps": round(st.sgs_stream_bytes / max(1e-9, st.sgs_ms_total * 1e-3) / 1e9, 2)}
 
     cpu = None

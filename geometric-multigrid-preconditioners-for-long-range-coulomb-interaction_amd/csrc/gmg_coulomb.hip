@@ -77,7 +77,7 @@ struct SgsPlan {
   std::vector<int32_t> host_block_row;  // n_blocks + 1 (several ranks: who sweeps which rows)
   double *w_stage = nullptr;            // staging of the all-gather of the swept pieces
   int64_t w_stage_len = 0;
-  // three-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
+  // four-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
   bool phased = false;
   PhRange *p_ranges = nullptr;
   uint4 *p_blk_tab = nullptr;
@@ -146,7 +146,7 @@ struct gmg_context {
   int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
   bool sgs_phase_nocascade = false;  // every step gathers all T1 slots of its shape (comparison)
   bool sgs_phase_nosplit = false;  // the whole tail is gathered in the dependent phase (comparison / tests)
-  int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the three-wave sweep (value - 1: timing experiment)
+  int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the four-wave sweep
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
   bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false;
@@ -821,7 +821,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
           HIPC(hipStreamSynchronize(ctx->stream));
           (void)hipFree(d);
           if (L.sgs.w_steps > 1000 && nbl == 1) {
-            std::fprintf(stderr, "[gmg] three-wave sweep, mode %d, %lld rows: per range dir G L steps | cycles/step | load+write-back cycles\n", q.mode, (long long)L.n);
+            std::fprintf(stderr, "[gmg] four-wave sweep, mode %d, %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", q.mode, (long long)L.n);
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
               const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
@@ -1194,7 +1194,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   SgsPlan &G = L.sgs;
   G.wave = false;
   if (n <= 0 || ctx->sgs_disable_wave) return GMG_OK;
-  // three waves in turn (gmg_sgs_phase.hpp) unless switched off; rows wider than its records hold fall back to one wave
+  // four waves in turn (gmg_sgs_phase.hpp) unless switched off; rows wider than its records hold fall back to one wave
   bool ph = allow_phase && !ctx->sgs_disable_phase && !ctx->sgs_profile;
   if (ph) {
     for (int64_t i = 0; i < n && ph; ++i) ph = rp[i + 1] - rp[i] <= 2 * kPhMaxEntries;  // (cheap pre-check; the exact one is per range)
@@ -1384,7 +1384,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
         R.groups = g_dir;
         R.n_steps = 0;
         if (ph) {
-          // ---- three-wave records.  step_of: the step (of this range) that updates a row; a row's TAIL starts at its first
+          // ---- four-wave records.  step_of: the step (of this range) that updates a row; a row's TAIL starts at its first
           // column updated by the step right before its own
           for (size_t st = s0; st < s1; ++st)
             for (int u = 0; u < steps[st].nrows; ++u) {
@@ -1684,7 +1684,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                  (long long)hist_l1[5], (long long)hist_l1[6], (long long)hist_l1[7], (long long)hist_l2[0], (long long)hist_l2[1], (long long)hist_l2[2], (long long)hist_l2[3]);
   if (ctx->debug_upload)
     std::fprintf(stderr, "[gmg] SGS %s plan: %lld rows, %lld coupled, %d blocks, %lld stages, %lld sub-steps, %d ranges, y slots %d, stream %.1f MB\n",
-                 ph ? "three-wave" : "wave", (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
+                 ph ? "four-wave" : "one-wave", (long long)n, (long long)G.w_n_coupled, n_blocks, (long long)total_stages, (long long)total_steps, G.w_n_ranges, y_slots,
                  (double)stream.size() / 1e6);
   return GMG_OK;
 }

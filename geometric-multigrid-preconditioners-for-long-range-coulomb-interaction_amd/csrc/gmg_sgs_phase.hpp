@@ -1,25 +1,34 @@
-// gmg_sgs_phase.hpp -- the SSOR wavefront sweep of gmg_sgs.hpp with the dependent steps taken in turn by THREE waves.
+// gmg_sgs_phase.hpp -- the SSOR wavefront sweep of gmg_sgs.hpp with the dependent steps taken in turn by FOUR waves.
 //
 // Reference: LA::MPI::PreconditionSSOR with AdditionalData(0.5), /root/reference/src/step-50.cc:970-973 (same
-// arithmetic, same order as gmg_sgs.hpp and oracle/gmg_oracle.c:smoother_apply_inverse).
+// arithmetic, same order as gmg_sgs.hpp and oracle/gmg_oracle.c:smoother_apply_inverse; bit-identical results).
 //
 // One wave pays ~1000 cycles per dependent step although the step's true dependence is short: of the ~14 products a
-// row adds, only the few whose column was updated by the PREVIOUS step cannot be formed in advance.  So a row's sum
-// is cut where its first such column stands (CSR order is kept): the HEAD -- everything before it -- needs nothing
-// from the previous step, the TAIL is that column and whatever follows it.  Three waves of one workgroup take the
-// steps in turn and meet at s_barrier once per PHASE; in phase p
-//     wave p % 3       finishes step p       (CRIT: gathers the tail's y, continues the sum, writes the new y to LDS),
-//     wave (p+1) % 3   prepares step p + 1   (P2: gathers the head's y, forms the head's partial sum),
-//     wave (p+2) % 3   fetches step p + 2    (P1: the step's records from its LDS region into registers, then starts
-//                                             the copy of its NEXT block, step p + 5, global -> LDS),
-// so that the dependent chain is barrier -> <= L gathers -> L multiply-adds -> one LDS store -> barrier.  The records
-// reach LDS by global_load_lds (no registers, no helper waves); a fourth wave touches the stream ~64 KB ahead so that
-// those copies hit the L2.  Nobody spins: every wave executes exactly n_steps + 2 barriers per range.
+// row adds, only the few whose column was updated by the PREVIOUS step cannot be formed in advance.  A row's sum is
+// therefore cut in three (CSR order is kept):
+//     HEAD  everything before its first "late" column (a column the previous step updates): gathered and summed ahead;
+//     T1    from the first late column to the last one: gathered, multiplied and added in the dependent phase;
+//     T2    what follows the last late column: products formed ahead, only ADDED in the dependent phase.
+// Four waves of one workgroup take the steps in turn and meet at s_barrier once per PHASE; wave w owns the steps
+// t = w, w + 4, ... and spends four phases on each:
+//     phase t - 3   P1    the step's records, LDS region of the wave -> registers
+//     phase t - 2   COPY  starts the copy of its next block (step t + 4) global -> the same LDS region (global_load_lds:
+//                         no registers, no helper waves; ~45 cycles per KB to issue, which is why it has a phase of its own)
+//     phase t - 1   P2    head: gathers + partial sum; T2: gathers + products
+//     phase t       CRIT  T1 gathers, T1 multiply-adds, T2 adds, the new y, one LDS store
+// so that in every phase one wave is in CRIT and the dependent chain is barrier -> <= L1 gathers -> L1 multiply-adds +
+// L2 adds -> one LDS store -> barrier.  A fifth wave touches the record stream ahead of the copies so that they hit
+// the L2.  Nobody spins: every wave executes exactly n_steps + 3 barriers per range.
 //
-// Forward sweep (columns j < i): the tail is short (level 1 of the 64 k-atom hierarchy: <= 11 entries per step, mean
-// 5), the head up to 24.  Backward sweep (columns j >= i, continuing the forward sum): the late columns are the
-// nearest upper neighbours, which come FIRST in CSR order, so nearly the whole row is tail (~22): the backward sweep
-// gains less.
+// Shapes.  The code of a step is straight-line for its shape (G groups of 8 head slots, L1, L2): 51 shapes x 2
+// directions are instantiated, the host picks per CHUNK of 32 steps the cheapest shape that holds every row (measured
+// phase costs), a row may give the end of its head / the start of its T2 to T1 to fit.  Changing the shape from one
+// turn to the next costs a wave ~400 cycles (another stretch of code): per-step shapes were measured and lost; inside a
+// shape the dependent phase still stops at the T1 slots the step really uses (pieces of four, one forward branch).
+//
+// Measured on the 64 k-atom hierarchy (level 1: 170 516 rows, 92 164 coupled, 4 384 stages; MI355X): 2.80 ms per sweep
+// pair against 4.78 ms for the one-wave sweep; per step ~700 cycles: forward CRIT ~390, backward ~580 (the late columns
+// of a backward row are its nearest upper neighbours, FIRST in CSR order: its T1 is longer), P1 ~600, COPY ~500.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

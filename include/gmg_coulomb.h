@@ -188,7 +188,7 @@ typedef struct gmg_stats {
   double spmv0_noop_ms_total;   /* ... their summed event time                                                */
   int64_t sgs_samples;          /* SSOR sweep launches (levels >= 1) bracketed by HIP events while profiling is on   */
   double sgs_ms_total;          /* their summed event time                                                           */
-  int64_t sgs_substeps;         /* dependent sub-steps those launches walked (the sweep is latency bound)            */
+  int64_t sgs_substeps;         /* dependent steps those launches walked (the sweep is latency bound)                */
   int64_t sgs_stream_bytes;     /* record bytes they streamed                                                        */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
