@@ -102,6 +102,56 @@ def test_smoother_epilogues_on_the_pattern_run_kernel(kind, name, from_zero):
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
 
 
+def _random_sparse(n, per_row, rng, reach):
+    """rows with ~per_row random columns within +-reach of the diagonal (ascending, diagonal included, some stored zeros)"""
+    rows = []
+    for i in range(n):
+        c = sorted(set(int(x) for x in np.clip(i + rng.integers(-reach, reach + 1, per_row), 0, n - 1)) | {i})
+        v = rng.standard_normal(len(c))
+        v[rng.random(len(c)) < 0.15] = 0.0
+        v[c.index(i)] = 4.0 + abs(v[c.index(i)])
+        rows.append((c, v))
+    return csr(n, n, rows)
+
+
+@pytest.mark.parametrize("blocks", [1, 4])
+@pytest.mark.parametrize("shape", ["chain", "wide-stages", "wide-rows", "scattered"])
+def test_ssor_on_synthetic_dependency_shapes(shape, blocks):
+    """The SSOR sweep on operators whose dependency graphs stress the four-wave sweep (gmg_sgs_phase.hpp) in ways the mesh
+    hierarchies do not, bit for bit against the oracle: a band of 27 consecutive columns (every stage is ONE row, every
+    lower neighbour is late), a sparse operator with hundreds of independent rows per stage (stages cut into steps of 32
+    rows), rows of 61 entries (more than a record holds: the plan falls back to the one-wave sweep), and scattered columns
+    (heads, T1 and T2 of every length)."""
+    rng = np.random.default_rng({"chain": 31, "wide-stages": 32, "wide-rows": 33, "scattered": 34}[shape])
+    n = 3000 + 17
+    if shape == "chain":
+        A1 = banded(n, 27, rng)
+    elif shape == "wide-stages":
+        A1 = _random_sparse(n, 3, rng, 700)
+    elif shape == "wide-rows":
+        A1 = banded(n, 61, rng)
+    else:
+        A1 = _random_sparse(n, 14, rng, 60)
+    A0 = banded(64, 3, rng)
+    P = csr(n, 64, [([i % 64], [1.0]) for i in range(n)])
+    idx = np.arange(n, dtype=np.int32)
+    hier = SimpleNamespace(system_matrix=A1, level_matrices=[A0, A1], edge_matrices=[None, None], prolongations=[P],
+                           copy_global=[np.zeros(0, dtype=np.int32), idx], copy_level=[np.zeros(0, dtype=np.int32), idx])
+    c = capi().Context(2)
+    c.set_tuning(ssor_blocks=blocks)
+    c.load_hierarchy(hier)
+    c.set_smoother(capi().SSOR, 0.5, 2)
+    mg = go.OracleMG(hier, smoother=go.SSOR, omega=0.5, steps=2, ssor_blocks=blocks)
+    u0, rhs = rng.standard_normal(n), rng.standard_normal(n)
+    for from_zero in (True, False):
+        ref = mg.smooth(1, u0, rhs, from_zero)
+        u, r = c.vector(n, u0), c.vector(n, rhs)
+        c.smoother_step(1, u, r, from_zero)
+        got = u.download()
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    c.close()
+
+
 def test_more_than_256_values_falls_back_to_fp64_values():
     rng = np.random.default_rng(12)
     m = banded(3000, 27, rng)  # random values: thousands of distinct doubles
