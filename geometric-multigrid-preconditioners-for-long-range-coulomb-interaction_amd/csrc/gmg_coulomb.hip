@@ -50,6 +50,7 @@ struct DevCSR {
   int32_t *sell_spat = nullptr, *sell_pat = nullptr;  // column-pattern ids per slice / pattern table
   int sellp_pid = -1, sellp_centre[9] = {};  // the nine-runs-of-three pattern served by spmv_sellp_kernel
   int32_t *sellp_wave_ptr = nullptr;          // slice range of every wave of spmv_sellp_kernel
+  int4 *sellp_wave_rr = nullptr;              // strided fast waves: {first slice, stride, pairs, one more slice or -1}
   bool use_sellp = false;
   bool rowclass = false;  // run-pattern slices take their coefficients from a per-row class table (N4)
   uint8_t *sellp_rowcls = nullptr;
@@ -151,6 +152,7 @@ struct gmg_context {
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
   bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false;
   int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
+  int sellp_rr = 0;         // round-robin slice order of the fast waves: 0 by size, 1 on, 2 off
   double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
   int ssor_blocks = 1;  // 1 = exact sequential SGS; B > 1 = block Jacobi of SGS (the reference on B ranks)
   int cg_variant = 0;  // 0 auto, 1 fused 2-kernel iteration, 2 unfused 3-kernel iteration
@@ -234,6 +236,7 @@ void free_csr(DevCSR &m) {
   if (m.tile_row) (void)hipFree(m.tile_row);
   if (m.slice_ptr) (void)hipFree(m.slice_ptr);
   if (m.sellp_wave_ptr) (void)hipFree(m.sellp_wave_ptr);
+  if (m.sellp_wave_rr) (void)hipFree(m.sellp_wave_rr);
   if (m.sellp_rowcls) (void)hipFree(m.sellp_rowcls);
   if (m.sellp_ctab) (void)hipFree(m.sellp_ctab);
   if (m.slice_base) (void)hipFree(m.slice_base);
@@ -598,6 +601,35 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
                 for (int32_t s2 = wp[(size_t)wv]; s2 < wp[(size_t)wv + 1] && all; ++s2) all = spat[(size_t)s2] == m.sellp_pid;
                 if (all) wp[(size_t)wv] |= kSellpFastWave;
               }
+              // Operators whose x does not fit an XCD's L2: the slices of consecutive fast waves of one XCD are dealt
+              // round-robin in pairs, so that at any time the XCD's waves sit inside a window of ~2 W slices (their x
+              // working set: three lattice planes instead of the XCD's whole eighth of x, which is then fetched once).
+              const bool rr = ctx->sellp_rr == 1 || (ctx->sellp_rr == 0 && n_rows * 8 / 8 > (int64_t)(3 << 20));
+              if (rr) {
+                const int per_xcd = n_waves / 8;
+                std::vector<int4> desc((size_t)n_waves, int4{0, 0, 0, -1});
+                for (int x = 0; x < 8; ++x) {
+                  int a0 = x * per_xcd;
+                  while (a0 < (x + 1) * per_xcd) {
+                    if (!(wp[(size_t)a0] & kSellpFastWave)) { ++a0; continue; }
+                    int b0 = a0;
+                    while (b0 + 1 < (x + 1) * per_xcd && (wp[(size_t)b0 + 1] & kSellpFastWave)) ++b0;
+                    const int wn = b0 - a0 + 1;
+                    const int32_t S0 = wp[(size_t)a0] & (kSellpFastWave - 1), S1 = wp[(size_t)b0 + 1] & (kSellpFastWave - 1);
+                    const int n_pairs = (S1 - S0) / 2;
+                    if (wn >= 2 && n_pairs >= wn) {
+                      for (int r = 0; r < wn; ++r) {
+                        desc[(size_t)(a0 + r)] = int4{S0 + 2 * r, 2 * wn, (n_pairs - r + wn - 1) / wn, -1};
+                        wp[(size_t)(a0 + r)] |= kSellpStrided;
+                      }
+                      if ((S1 - S0) & 1) desc[(size_t)b0].w = S1 - 1;
+                    }
+                    a0 = b0 + 1;
+                  }
+                }
+                HIPC(hipMalloc(&m.sellp_wave_rr, sizeof(int4) * desc.size()));
+                HIPC(hipMemcpyAsync(m.sellp_wave_rr, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
+              }
             }
           }
           HIPC(hipMalloc(&m.sellp_wave_ptr, sizeof(int32_t) * wp.size()));
@@ -668,7 +700,7 @@ int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
     SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
     if (m.use_sellp) {
       SellPatArgs pa{};
-      pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
+      pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.wave_rr = m.sellp_wave_rr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
       for (int u = 0; u < 9; ++u) pa.centre[u] = m.sellp_centre[u];
       pa.rowcls = m.sellp_rowcls; pa.ctab = m.sellp_ctab; pa.n_classes = m.n_classes;
       if (m.rowclass) launch_timed(ctx, spmv_sellp_kernel<MODE, CG, true>, dim3(m.sell_grid), dim3(kThreads), 0, pa);
@@ -2442,6 +2474,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "disable_rowclass") ctx->disable_rowclass = on;
   else if (k == "sell_grid") ctx->sell_grid = (int)value;
   else if (k == "sellp_cost") ctx->sellp_cost = value;
+  else if (k == "sellp_rr") ctx->sellp_rr = (int)value;
   else if (k == "cg_variant") ctx->cg_variant = (int)value;
   else if (k == "coarse_chunk") ctx->coarse_chunk = (int)value;
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;

@@ -523,6 +523,7 @@ struct SellPatArgs {
   const double *ctab;     // RC: [n_classes][27] coefficients in entry order (exact copies of the dictionary values)
   int n_classes;
   const int32_t *wave_ptr;  // [gridDim.x * 4 + 1]: slice range of every wave (XCD-major, balanced by slice cost on the host)
+  const int4 *wave_rr;      // strided fast waves: {first slice, stride, pairs, one more slice or -1}
   int pid0;        // the pattern served by the fast path
   int centre[9];   // column offset (relative to the row) of the centre entry of each of its nine runs
   int col16;       // layout of the column stream used by the other slices
@@ -559,6 +560,7 @@ __device__ __forceinline__ double lane_double(double v, int l) {  // l: wave-uni
 }
 
 constexpr int kSellpWaves = 4;  // resident waves per SIMD (= workgroups per CU) the register budget of the kernel is set for
+constexpr int kSellpStrided = 0x20000000;   // flag in wave_ptr[w]: the wave's pairs of slices are described by wave_rr[w]
 constexpr int kSellpFastWave = 0x40000000;  // flag in wave_ptr[w]: every slice of wave w is a run-pattern slice with row classes
 
 // RC (row classes): on a lattice the rows of the run-pattern slices have few distinct coefficient
@@ -588,8 +590,8 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_se
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
   const int w = (xcd * nb + lb) * 4 + wid;
   const int e0 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w]);
-  const int s0 = e0 & (kSellpFastWave - 1);
-  const int s1 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w + 1]) & (kSellpFastWave - 1);  // s1 - s0 <= 64 (host)
+  const int s0 = e0 & (kSellpStrided - 1);
+  const int s1 = __builtin_amdgcn_readfirstlane(pa.wave_ptr[w + 1]) & (kSellpStrided - 1);  // s1 - s0 <= 64 (host)
   const bool fast = RC && (e0 & kSellpFastWave) != 0;
   const uchar4 *kbase = reinterpret_cast<const uchar4 *>(sa.vals) + lane;
   const double *xb[9], *gb[9];
@@ -655,9 +657,16 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_se
   bool a_ready = false;
   // slice metadata of the whole wave in one round trip, together with the dictionary: lane i <-> slice s0 + i
   int m_qb = 0, m_qe = 0, m_pid = -1;
+  // a fast wave's pairs of slices: rr_first + k rr_stride, k < rr_n, then possibly one more slice
+  int rr_first = s0, rr_stride = 2, rr_n = (s1 - s0) >> 1, rr_extra = ((s1 - s0) & 1) ? s1 - 1 : -1;
   if (fast) {
     m_pid = pa.pid0;
-    if (!XFORM && s0 + 1 < s1) { issue_pair(s0, A); a_ready = true; }
+    if (e0 & kSellpStrided) {
+      const int4 d = pa.wave_rr[w];
+      rr_first = __builtin_amdgcn_readfirstlane(d.x); rr_stride = __builtin_amdgcn_readfirstlane(d.y);
+      rr_n = __builtin_amdgcn_readfirstlane(d.z); rr_extra = __builtin_amdgcn_readfirstlane(d.w);
+    }
+    if (!XFORM && rr_n > 0) { issue_pair(rr_first, A); a_ready = true; }
   } else if (s0 + lane < s1) {
     m_qb = sa.qptr[s0 + lane];
     m_qe = sa.qptr[s0 + lane + 1];
@@ -757,20 +766,23 @@ __global__ __launch_bounds__(kThreads, (CG == 1 ? 3 : kSellpWaves)) void spmv_se
       }
     }
   };
-  int s_begin = s0;
+  int s_begin = s0, s_end = s1;
   if (fast) {
     // nothing but pairs (and at most one slice after them): the first pair's loads are already in flight
     XPair P = A;
-    for (; s_begin + 1 < s1; s_begin += 2) {
-      if (!a_ready) issue_pair(s_begin, P);
+    for (int k = 0; k < rr_n; ++k) {
+      const int sp = rr_first + k * rr_stride;
+      if (!a_ready) issue_pair(sp, P);
       a_ready = false;
-      sum_pair(s_begin, P);
+      sum_pair(sp, P);
     }
+    s_begin = rr_extra >= 0 ? rr_extra : 0;
+    s_end = rr_extra >= 0 ? rr_extra + 1 : 0;
   }
-  for (int s = s_begin; s < s1;) {
-    const int i = s - s0;
+  for (int s = s_begin; s < s_end;) {
+    const int i = fast ? 0 : s - s0;  // (a fast wave holds the same metadata in every lane)
     const int pid = __builtin_amdgcn_readlane(m_pid, i);
-    if (RC && pid == pa.pid0 && s + 1 < s1 && __builtin_amdgcn_readlane(m_pid, i + 1) == pa.pid0) {
+    if (RC && !fast && pid == pa.pid0 && s + 1 < s_end && __builtin_amdgcn_readlane(m_pid, i + 1) == pa.pid0) {
       XPair P;
       issue_pair(s, P);
       sum_pair(s, P);

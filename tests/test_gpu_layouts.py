@@ -53,21 +53,22 @@ def banded(n, width, rng, distinct=None, spread=1, n_classes=0):
 
 
 @pytest.mark.parametrize("case,expect", [
-    ("val8_col16_runs", 1 + 2 + 4 + 8), ("val8_col16_rowclass", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_codes", 1 + 2 + 4 + 8), ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
+    ("val8_col16_runs", 1 + 2 + 4 + 8), ("val8_col16_rowclass", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_rr", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_codes", 1 + 2 + 4 + 8), ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
 ])
 def test_sell_variants_bit_exact(case, expect):
     """27 consecutive columns per row are nine runs of three: with 8-bit value codes that operator goes to
     the pattern-run kernel (layout bit 8) unless the diagnostic switch keeps it on the per-entry kernel.  When the rows
     have few distinct coefficient vectors (a lattice: here 7 of them) the kernel runs with row classes (bit 16: one
     class byte per row instead of one code per entry) unless those are switched off; random values per entry give far
-    more than 96 classes and stay on the codes."""
+    more than 96 classes and stay on the codes.  `_rr`: the round-robin slice order large lattices get (here forced; a
+    bigger operator so that every wave owns several pairs of slices)."""
     rng = np.random.default_rng(11)
-    n = 5000 + 37  # not a multiple of 64
+    n = (5000 if not case.endswith("_rr") else 700000) + 37  # not a multiple of 64
     distinct = np.array([-1 / 6, -1 / 12, 8 / 3, 0.0, 1.25]) if "val8" in case else None
     spread = 1 if "col16" in case else 3000  # 27 * 3000 > 65535 columns within a slice
     m = banded(n if spread == 1 else 200000, 27, rng, distinct, spread, n_classes=7 if "rowclass" in case else 0)
     x = rng.standard_normal(m.n_cols)
-    y, lay = apply_level0(m, x, ("disable_sellp",) if case == "val8_col16" else ("disable_rowclass",) if case.endswith("_codes") else ())
+    y, lay = apply_level0(m, x, ("disable_sellp",) if case == "val8_col16" else ("disable_rowclass",) if case.endswith("_codes") else ("sellp_rr",) if case.endswith("_rr") else ())
     assert lay == expect, (case, lay)
     assert np.array_equal(y, go.spmv(m, x))
 
