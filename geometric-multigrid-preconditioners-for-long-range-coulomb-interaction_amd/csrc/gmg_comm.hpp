@@ -163,7 +163,13 @@ inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
     c.cap = c.boot->cap_bytes;
     c.rank = rank; c.n_ranks = n_ranks;
     const size_t bytes = (size_t)kPeerFlagBytes + 2 * (size_t)n_ranks * (size_t)c.cap;
-    if (hipMalloc((void **)&c.box[rank], bytes) != hipSuccess) return 1;
+    // The mailbox is polled by kernels of this GPU while kernels of OTHER GPUs store into it: fine-grained (coherent across
+    // devices while kernels run) where the runtime offers it.  (The shared direction vectors are read only after the kernel
+    // that waited for their tags has ended: ordinary memory.)
+    if (hipExtMallocWithFlags((void **)&c.box[rank], bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc((void **)&c.box[rank], bytes) != hipSuccess) return 1;
+    }
     if (hipMemset(c.box[rank], 0, (size_t)kPeerFlagBytes) != hipSuccess) return 1;
     if (hipMalloc((void **)&c.cnt, sizeof(unsigned int) * 2 * kPeerMaxRanks) != hipSuccess) return 1;
     if (hipMemset(c.cnt, 0, sizeof(unsigned int) * 2 * kPeerMaxRanks) != hipSuccess) return 1;
