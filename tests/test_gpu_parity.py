@@ -241,7 +241,7 @@ def test_single_rank_communicator_path(hier45):
                                             (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
 def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the device
-    variants: the three-wave sweep (gmg_sgs_phase.hpp, the default) and the one-wave sweep (gmg_sgs.hpp), each with a
+    variants: the four-wave sweep (gmg_sgs_phase.hpp, the default) and the one-wave sweep (gmg_sgs.hpp), each with a
     block's rows in one LDS range and with the LDS budget cut to 300 doubles so that every block is swept in many
     ranges (working sets written back / reloaded in between), and the generic CSR sweep."""
     level = 4

@@ -1,5 +1,5 @@
 #!/bin/bash
-# three-wave SSOR sweep: parity first, then the sweep timings (one-wave sweep beside it) and a short bench
+# four-wave SSOR sweep: parity first, then the sweep timings (one-wave sweep beside it) and a short bench
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
