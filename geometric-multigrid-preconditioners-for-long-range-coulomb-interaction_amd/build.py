@@ -35,6 +35,7 @@ def _sources(d, exts):
 def build_device(force=False, verbose=False):
     srcs = _sources(CSRC, (".hip", ".hpp")) + [os.path.join(HERE, "..", "include", "gmg_coulomb.h")]
     if force or _newer(LIB_DEVICE, srcs):
+        # -fno-jump-tables: the per-turn shape dispatch of the SSOR sweep as compares, not as a table read from memory
         cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off", "-fno-jump-tables", "-std=c++17",
                "-Wall", "-Wno-unused-function", "-o", LIB_DEVICE, os.path.join(CSRC, "gmg_coulomb.hip"),
                "-pthread", "-L" + os.path.join(ROCM, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]

@@ -111,29 +111,6 @@ __device__ __forceinline__ void copy_to_lds(const char *src, uint32_t dst, uint3
   }
 }
 
-// waits until at most k vector-memory operations of this wave are in flight (k: wave-uniform, 0..16)
-__device__ __forceinline__ void wait_all_but(int k) {
-  switch (k) {
-    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
-    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
-    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
-    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
-    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
-    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
-    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
-    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
-    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
-    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
-    case 13: __builtin_amdgcn_s_waitcnt(0x0f7d); break;
-    case 14: __builtin_amdgcn_s_waitcnt(0x0f7e); break;
-    case 15: __builtin_amdgcn_s_waitcnt(0x0f7f); break;
-    default: __builtin_amdgcn_s_waitcnt(0x4f70); break;  // vmcnt(16)
-  }
-}
-
 template <int G, int L>
 struct Rec {
   double hv[G > 0 ? 8 * G : 1], tv[L];
