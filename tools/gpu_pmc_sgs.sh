@@ -14,7 +14,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$R/gpurun_out/pmc_sgs/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "sgs_wave_kernel" in r["Kernel_Name"]:
+        if "sgs_phase_kernel" in r["Kernel_Name"] or "sgs_wave_kernel<" in r["Kernel_Name"]:
             agg[r["Counter_Name"]][int(r["Grid_Size"]) if "Grid_Size" in r else 0].append(float(r["Counter_Value"]))
 for c, v in sorted(agg.items()):
     for g, vals in v.items():
