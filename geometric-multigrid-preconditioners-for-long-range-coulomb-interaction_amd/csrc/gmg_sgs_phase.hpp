@@ -138,7 +138,10 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
   unsigned long long m1 = 0;
 #define PH_T(acc) if (timed) { m1 = __builtin_amdgcn_s_memtime(); T.acc += m1 - T.m0; T.m0 = m1; }
   // ---- P1: records -> registers
-  if (FWD && !first) __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): my block has arrived; the prefix store of my last step may be on its way
+  // vmcnt counts this wave's vector-memory operations in issue order (gfx9: loads, LDS copies and stores share the counter):
+  // all but the newest one done = the block has arrived; the prefix store of my last step may still be on its way (waiting
+  // for it too costs 4 % of the sweep)
+  if (FWD && !first) __builtin_amdgcn_s_waitcnt(0x0f71);
   else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
   PH_T(c_wait)
   {
