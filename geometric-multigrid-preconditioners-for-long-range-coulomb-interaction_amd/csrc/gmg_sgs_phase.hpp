@@ -129,14 +129,14 @@ struct Turn {
 __host__ __device__ constexpr int ph_key(int g, int l1, int l2) { return g * 64 + (l1 / 4) * 8 + l2 / 8; }
 
 // One step of shape (G, L1, L2) by one wave: four phases, four barriers.
-template <int G, int L1, int L2, bool FWD>
-__device__ __forceinline__ void turn(Turn &T, bool first, const char *base, double *stream_d, uint32_t region, int lane, double omega, bool timed) {
+template <int G, int L1, int L2, bool FWD, bool TIMED>
+__device__ __forceinline__ void turn(Turn &T, bool first, const char *base, double *stream_d, uint32_t region, int lane, double omega) {
   constexpr int L = L1 + L2;
   constexpr uint32_t stride = (uint32_t)ph_stride(G, L);
   Rec<G, L> C;
   int l1s = L1;  // T1 slots this step really uses (multiple of 4): the dependent phase stops there
   unsigned long long m1 = 0;
-#define PH_T(acc) if (timed) { m1 = __builtin_amdgcn_s_memtime(); T.acc += m1 - T.m0; T.m0 = m1; }
+#define PH_T(acc) if constexpr (TIMED) { m1 = __builtin_amdgcn_s_memtime(); T.acc += m1 - T.m0; T.m0 = m1; }
   // ---- P1: records -> registers
   // vmcnt counts this wave's vector-memory operations in issue order (gfx9: loads, LDS copies and stores share the counter):
   // all but the newest one done = the block has arrived; the prefix store of my last step may still be on its way (waiting
@@ -236,7 +236,7 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
       if constexpr (FWD) stream_d[C.aux] = acc;
     }
   }
-  if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); }
+  if constexpr (TIMED) { __builtin_amdgcn_s_waitcnt(0xc07f); }
   PH_T(c_crit)
   bar();
   PH_T(c_bar)
@@ -245,7 +245,7 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
 
 // The steps t = w, w + 4, ... of a range by compute wave w.  Every step has its own shape (its key travels in the header
 // of the wave's previous block): one indirect branch per turn, in the phase that only reads records.
-template <bool FWD>
+template <bool FWD, bool TIMED>
 __device__ __forceinline__ void sweep(const PhRange *R, const uint4 *tab, const char *stream, double *stream_d, uint32_t region, int w, int lane, double omega,
                                       unsigned long long *tp) {
   const int n = R->n_steps;
@@ -259,13 +259,12 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint4 *tab, const 
   }
   for (int i = 0; i < w; ++i) bar();
   int done = w;
-  const bool timed = tp != nullptr;
-  if (timed) T.m0 = __builtin_amdgcn_s_memtime();
+  if constexpr (TIMED) T.m0 = __builtin_amdgcn_s_memtime();
   while (t < n) {
 #define PH_CASE(g, l1, l2) \
     case ph_key(g, l1, l2): \
       do { \
-        turn<g, l1, l2, FWD>(T, t == w, base, stream_d, region, lane, omega, timed); \
+        turn<g, l1, l2, FWD, TIMED>(T, t == w, base, stream_d, region, lane, omega); \
         t += kPhWaves; done += kPhWaves; \
       } while (t < n && T.key == ph_key(g, l1, l2));  /* (steps of one shape in a row: no dispatch in between) */ \
       break;
@@ -287,7 +286,7 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint4 *tab, const 
 #undef PH_CASE
   }
   for (; done < n + kPhWaves - 1; ++done) bar();
-  if (tp && w == 0 && lane == 0) { tp[0] = T.c_wait; tp[1] = T.c_p1; tp[2] = T.c_copy; tp[3] = T.c_p2; tp[4] = T.c_crit; tp[5] = T.c_bar; }
+  if (TIMED && tp && w == 0 && lane == 0) { tp[0] = T.c_wait; tp[1] = T.c_p1; tp[2] = T.c_copy; tp[3] = T.c_p2; tp[4] = T.c_crit; tp[5] = T.c_bar; }
 }
 
 }  // namespace ph
@@ -322,8 +321,15 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     if (wid < kPhWaves) {
       double *stream_d = reinterpret_cast<double *>(a.stream);
       const uint32_t region = ring0 + (uint32_t)wid * (uint32_t)kPhRegion;
-      if (R.backward) ph::sweep<false>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
-      else ph::sweep<true>(Rp, a.blk_tab + Rp->blk_tab, a.stream, stream_d, region, wid, lane, a.omega, a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr);
+      unsigned long long *tp = a.prof ? a.prof + 12 * (size_t)rg + 4 : nullptr;
+      const uint4 *tab = a.blk_tab + Rp->blk_tab;
+      if (tp) {  // (the instrumented variant is code of its own: the production sweep carries no timer branches)
+        if (R.backward) ph::sweep<false, true>(Rp, tab, a.stream, stream_d, region, wid, lane, a.omega, tp);
+        else ph::sweep<true, true>(Rp, tab, a.stream, stream_d, region, wid, lane, a.omega, tp);
+      } else {
+        if (R.backward) ph::sweep<false, false>(Rp, tab, a.stream, stream_d, region, wid, lane, a.omega, nullptr);
+        else ph::sweep<true, false>(Rp, tab, a.stream, stream_d, region, wid, lane, a.omega, nullptr);
+      }
     } else {
       // prefetch wave: one 4-byte copy per 128-byte line, pf_step bytes per phase, into the junk area
       const char *base = a.stream + R.stream_off;
