@@ -1509,6 +1509,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           const int64_t base = ((int64_t)stream.size() + 1023) / 1024 * 1024;
           P.stream_off = base;
           std::vector<int64_t> boff, bbytes;
+          std::vector<uint32_t> step_word;  // shape key | rows << 8 | T1 slots in use << 16
           int64_t off = 0;
           size_t tix = 0;
           for (size_t st = s0; st < s1; ++st) {
@@ -1526,7 +1527,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               t1_used = std::max(t1_used, h1 - h0);
             }
             t1_used = ctx->sgs_phase_nocascade ? L1r : std::min(L1r, std::max(4, (t1_used + 3) / 4 * 4));
-            reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)S.nrows | ((uint32_t)t1_used << 16);
+            step_word.push_back((uint32_t)ph::ph_key(Gr, L1r, sh.l2) | ((uint32_t)S.nrows << 8) | ((uint32_t)t1_used << 16));
             for (int u = 0; u < S.nrows; ++u) {
               const int i = seq[(size_t)(S.first + u)];
               const int32_t ci = row_ci[(size_t)(rb + i)];
@@ -1565,11 +1566,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           P.blk_tab = (uint32_t)blk_tab.size();
           for (size_t q = 0; q < boff.size(); ++q) {
             const Shape sh = shape_of[q];
-            blk_tab.push_back(uint4{(uint32_t)boff[q], (uint32_t)bbytes[q], (uint32_t)ph::ph_key(sh.g, sh.l1, sh.l2), 0u});
+            blk_tab.push_back(uint4{(uint32_t)boff[q], (uint32_t)bbytes[q], step_word[q], 0u});
             uint32_t *h = reinterpret_cast<uint32_t *>(stream.data() + base + boff[q]);
             if (q + kPhWaves < boff.size()) {  // the block its reader copies next, and that step's shape
-              const Shape nx = shape_of[q + kPhWaves];
-              h[1] = (uint32_t)bbytes[q + kPhWaves]; h[2] = (uint32_t)boff[q + kPhWaves]; h[3] = (uint32_t)ph::ph_key(nx.g, nx.l1, nx.l2);
+              h[1] = (uint32_t)bbytes[q + kPhWaves]; h[2] = (uint32_t)boff[q + kPhWaves]; h[3] = step_word[q + kPhWaves];
             }
             hist_l1[(size_t)std::min(7, sh.l1 / 4)]++; hist_l2[(size_t)(sh.l2 / 8)]++; hist_g[(size_t)sh.g]++;
           }

@@ -53,7 +53,8 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 }
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.  A step's block: 16-byte
-// header {nrows | T1 slots in use << 16, bytes of the block four steps on (0: none), its offset in the range's stream, its shape key}, then one record
+// header {-, bytes of the block four steps on (0: none), its offset in the range's stream, that step's shape key | rows << 8 |
+// T1 slots in use << 16}, then one record
 // per row:  +0 r  +8 1/a_ii  +16 prefix (backward: the forward sweep's sum)  +24 u32 LDS address of the row's y
 //           +28 u32 aux (forward: index, in doubles, of the prefix field of the row's backward record)
 //           +32 head values [8 G]   tail values [L]   head LDS addresses u32 [8 G]   tail LDS addresses u32 [L]
@@ -123,7 +124,7 @@ struct Rec {
 // what a wave carries from one of its steps to the next
 struct Turn {
   uint32_t nx_off, nx_bytes;  // its next block in the range's stream (bytes 0: none)
-  int key;                    // shape of its next step
+  int key;                    // its next step: shape | rows << 8 | T1 slots in use << 16 (so that P1 does not wait for the header)
   unsigned long long c_wait, c_p1, c_copy, c_p2, c_crit, c_bar, m0;
 };
 __host__ __device__ constexpr int ph_key(int g, int l1, int l2) { return g * 64 + (l1 / 4) * 8 + l2 / 8; }
@@ -145,12 +146,9 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
   else __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
   PH_T(c_wait)
   {
-    const u32x4 hdr = lds_ld<u32x4>(region);
-    const int h0 = __builtin_amdgcn_readfirstlane((int)hdr.x);
-    C.nrows = h0 & 0xffff;
-    l1s = h0 >> 16;
-    T.nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); T.nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
-    T.key = __builtin_amdgcn_readfirstlane((int)hdr.w);
+    C.nrows = (T.key >> 8) & 0xff;
+    l1s = T.key >> 16;
+    const u32x4 hdr = lds_ld<u32x4>(region);  // (about the wave's NEXT step: looked at after the reads below)
     const uint32_t rec = region + 16u + (uint32_t)min(lane, C.nrows - 1) * stride;
     const f64x2 ri = lds_ld<f64x2>(rec);
     const u32x4 q = lds_ld<u32x4>(rec + 16);
@@ -178,6 +176,8 @@ __device__ __forceinline__ void turn(Turn &T, bool first, const char *base, doub
       C.ta[4 * j] = c.x; C.ta[4 * j + 1] = c.y; C.ta[4 * j + 2] = c.z; C.ta[4 * j + 3] = c.w;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // every read of the region is done: it may be overwritten
+    T.nx_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y); T.nx_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.z);  // block t + 4
+    T.key = __builtin_amdgcn_readfirstlane((int)hdr.w);
     PH_T(c_p1)
   }
   bar();
@@ -266,9 +266,9 @@ __device__ __forceinline__ void sweep(const PhRange *R, const uint4 *tab, const 
       do { \
         turn<g, l1, l2, FWD, TIMED>(T, t == w, base, stream_d, region, lane, omega); \
         t += kPhWaves; done += kPhWaves; \
-      } while (t < n && T.key == ph_key(g, l1, l2));  /* (steps of one shape in a row: no dispatch in between) */ \
+      } while (t < n && (T.key & 0xff) == ph_key(g, l1, l2));  /* (steps of one shape in a row: no dispatch in between) */ \
       break;
-    switch (T.key) {
+    switch (T.key & 0xff) {
       PH_CASE(0, 4, 0) PH_CASE(0, 4, 8) PH_CASE(0, 4, 16) PH_CASE(0, 4, 24) PH_CASE(0, 8, 0) PH_CASE(0, 8, 8)
       PH_CASE(0, 8, 16) PH_CASE(0, 8, 24) PH_CASE(0, 12, 0) PH_CASE(0, 12, 8) PH_CASE(0, 12, 16) PH_CASE(0, 12, 24)
       PH_CASE(0, 16, 0) PH_CASE(0, 16, 8) PH_CASE(0, 16, 16) PH_CASE(0, 20, 0) PH_CASE(0, 20, 8) PH_CASE(0, 20, 16)
