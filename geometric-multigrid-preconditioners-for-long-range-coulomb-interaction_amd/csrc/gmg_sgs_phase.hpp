@@ -26,8 +26,8 @@
 // turn to the next costs a wave ~400 cycles (another stretch of code): per-step shapes were measured and lost; inside a
 // shape the dependent phase still stops at the T1 slots the step really uses (pieces of four, one forward branch).
 //
-// Measured on the 64 k-atom hierarchy (level 1: 170 516 rows, 92 164 coupled, 4 384 stages; MI355X): 2.80 ms per sweep
-// pair against 4.78 ms for the one-wave sweep; per step ~700 cycles: forward CRIT ~390, backward ~580 (the late columns
+// Measured on the 64 k-atom hierarchy (level 1: 170 516 rows, 92 164 coupled, 4 384 stages; MI355X): 2.47 ms per sweep
+// pair against 4.78 ms for the one-wave sweep; per step ~625 cycles (parts as the instrumented variant sees them): forward CRIT ~390, backward ~580 (the late columns
 // of a backward row are its nearest upper neighbours, FIRST in CSR order: its T1 is longer), P1 ~600, COPY ~500.
 #pragma once
 #include <hip/hip_runtime.h>
