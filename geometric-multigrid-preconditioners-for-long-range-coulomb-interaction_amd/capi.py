@@ -27,7 +27,7 @@ SYMBOLS = [
     "gmg_vec_add", "gmg_vec_sadd", "gmg_vec_dot", "gmg_vec_norms", "gmg_vec_all_zero",
     "gmg_spmv", "gmg_precondition", "gmg_precondition_jacobi", "gmg_coarse_solve", "gmg_smoother_step",
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
-    "gmg_comm_unique_id", "gmg_comm_init", "gmg_comm_barrier", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
+    "gmg_comm_unique_id", "gmg_comm_init", "gmg_comm_barrier", "gmg_comm_info", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
     "gmg_vec_allgather",
     "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_option", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density",
 ]
@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("coarse_variant", C.c_int64), ("spmv0_layout", C.c_int64), ("spmv0_matrix_bytes", C.c_int64),
                 ("spmv0_pattern_slices", C.c_int64), ("spmv0_slices", C.c_int64), ("coarse_enqueued", C.c_int64),
                 ("spmv0_noop_samples", C.c_int64), ("spmv0_noop_ms_total", C.c_double),
-                ("sgs_samples", C.c_int64), ("sgs_ms_total", C.c_double), ("sgs_substeps", C.c_int64), ("sgs_stream_bytes", C.c_int64)]
+                ("sgs_samples", C.c_int64), ("sgs_ms_total", C.c_double), ("sgs_substeps", C.c_int64), ("sgs_stream_bytes", C.c_int64),
+                ("sgs_launches", C.c_int64)]
 
 
 class GMGError(RuntimeError):
@@ -56,7 +57,8 @@ def load(build_if_missing: bool = False):
     """dlopen libgmgcoulomb.so from the source tree.  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        path = _build.LIB_DEVICE
+        # (GMG_DEVICE_LIB: measurement scripts only -- tools/build_experiments.sh; the host-side C++ always links the shipped library)
+        path = os.environ.get("GMG_DEVICE_LIB") or _build.LIB_DEVICE
         if build_if_missing:
             _build.build_device()
         if not os.path.exists(path):
@@ -262,6 +264,13 @@ class Context:
     def comm_init(self, rank, n_ranks, uid: bytes):
         buf = C.create_string_buffer(uid, UNIQUE_ID_BYTES)
         self._chk(self.L.gmg_comm_init(self.h, C.c_int(rank), C.c_int(n_ranks), buf))
+
+    def comm_info(self) -> dict:
+        out = (C.c_int64 * 8)()
+        self._chk(self.L.gmg_comm_info(self.h, out))
+        return {"ranks": int(out[0]), "transport": {0: "none", 1: "rccl", 2: "peer"}[int(out[1])], "mailbox_finegrained": bool(out[2]),
+                "ring_memory": {-1: "not allocated", 0: "hipMalloc (coarse-grained)", 1: "fine-grained"}[int(out[3])],
+                "devices": int(out[4]), "level0_partitioned": bool(out[5])}
 
     def set_global_sizes(self, n_system, n_level0):
         self._chk(self.L.gmg_set_global_sizes(self.h, C.c_int64(n_system), C.c_int64(n_level0)))

@@ -14,8 +14,14 @@
 //     waits for the acknowledgement of the message two rounds back before it reuses a buffer.  Measured
 //     (tools/micro/ipc_probe.hip): 2.6 us one way between two processes.  Unlike RCCL this transport also works
 //     between processes that share ONE GPU, which is how the rank-parallel layout is tested on a single-GPU box
-//     (tests/test_gpu_two_ranks.py).  Every wait inside a kernel is bounded: a rank that waits > ~1 s raises an
-//     abort flag the host reports as GMG_ERR_COMM instead of hanging the GPU.
+//     (tests/test_gpu_two_ranks.py).  Every wait inside a kernel is bounded (kPeerSpinLimit polls, ~15 s): a rank that
+//     gives up raises an abort flag the host reports as GMG_ERR_COMM instead of hanging the GPU.
+//     Memory: everything a peer's kernel stores into -- the mailbox and the coarse CG's shared direction ring -- is
+//     allocated FINE-GRAINED (hipExtMallocWithFlags, hipDeviceMallocFinegrained: coherent across devices while kernels
+//     run).  Ranks on DIFFERENT devices refuse to start on coarse-grained memory (comm_init compares the PCI bus ids
+//     the ranks publish in the boot segment); ranks sharing one device (the single-GPU test layout) may fall back to
+//     plain hipMalloc, where the device's own L2 is the point of coherence.  GMG_PEER_COARSE=1 forces plain hipMalloc
+//     (measurement of what fine-grained costs the SpMV; refused across devices).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -49,6 +55,8 @@ struct PeerBoot {  // zero-filled by ftruncate
   hipIpcMemHandle_t handle[kPeerMaxRanks];
   hipIpcMemHandle_t shared_handle[kPeerMaxRanks];  // comm_share_alloc: one collective allocation at a time
   int64_t meta[kPeerMaxRanks][4 + kPeerMaxRanks];  // comm_exchange_meta
+  int64_t dev_uid[kPeerMaxRanks];                  // PCI domain / bus / device of every rank's GPU (same value: the ranks share it)
+  int32_t fine[kPeerMaxRanks];                     // 1: that rank's mailbox is fine-grained memory
 };
 
 struct Comm {
@@ -65,7 +73,22 @@ struct Comm {
   unsigned long long last_sent[kPeerMaxRanks][2] = {};  // round of my last message to a peer, per parity
   unsigned int *cnt = nullptr;    // device: workgroups done, per peer (last one publishes)
   int *abort_host = nullptr;      // pinned: set by a kernel that gave up waiting
+  bool box_fine = false;          // my mailbox is fine-grained memory
+  int ring_fine = -1;             // the shared direction ring: -1 not allocated, 0 plain hipMalloc, 1 fine-grained
+  int n_devices = 1;              // distinct GPUs under the ranks
+  char why[160] = {};             // text of the last start-up failure
 };
+
+// memory a peer's kernels store into while my kernels run: fine-grained where the runtime offers it
+inline int peer_alloc(void **p, size_t bytes, bool *fine) {
+  const char *coarse = std::getenv("GMG_PEER_COARSE");
+  *fine = false;
+  if (!(coarse && coarse[0] == '1')) {
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) { *fine = true; return 0; }
+    (void)hipGetLastError();
+  }
+  return hipMalloc(p, bytes) != hipSuccess;
+}
 
 inline int boot_barrier(PeerBoot *b, int n_ranks) {
   const int gen = b->generation.load(std::memory_order_acquire);
@@ -163,12 +186,16 @@ inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
     c.cap = c.boot->cap_bytes;
     c.rank = rank; c.n_ranks = n_ranks;
     const size_t bytes = (size_t)kPeerFlagBytes + 2 * (size_t)n_ranks * (size_t)c.cap;
-    // The mailbox is polled by kernels of this GPU while kernels of OTHER GPUs store into it: fine-grained (coherent across
-    // devices while kernels run) where the runtime offers it.  (The shared direction vectors are read only after the kernel
-    // that waited for their tags has ended: ordinary memory.)
-    if (hipExtMallocWithFlags((void **)&c.box[rank], bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      if (hipMalloc((void **)&c.box[rank], bytes) != hipSuccess) return 1;
+    // The mailbox is polled by kernels of this GPU while kernels of OTHER GPUs store into it: fine-grained memory.
+    if (peer_alloc((void **)&c.box[rank], bytes, &c.box_fine)) return 1;
+    {
+      int dev = 0;
+      char bus[64] = {};
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) return 1;
+      int64_t uid = 1469598103934665603ll;  // FNV-1a of the bus id string ("0000:c1:00.0")
+      for (const char *q = bus; *q; ++q) uid = (uid ^ (unsigned char)*q) * 1099511628211ll;
+      c.boot->dev_uid[rank] = uid;
+      c.boot->fine[rank] = c.box_fine ? 1 : 0;
     }
     if (hipMemset(c.box[rank], 0, (size_t)kPeerFlagBytes) != hipSuccess) return 1;
     if (hipMalloc((void **)&c.cnt, sizeof(unsigned int) * 2 * kPeerMaxRanks) != hipSuccess) return 1;
@@ -178,8 +205,28 @@ inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
     if (hipIpcGetMemHandle(&c.boot->handle[rank], c.box[rank]) != hipSuccess) return 1;
     if (boot_barrier(c.boot, n_ranks)) return 1;
+    {
+      // every rank sees every rank's device and memory type: the same verdict everywhere, before anything is mapped
+      c.n_devices = 0;
+      bool all_fine = true;
+      for (int r = 0; r < n_ranks; ++r) {
+        bool seen = false;
+        for (int q = 0; q < r; ++q) seen = seen || c.boot->dev_uid[q] == c.boot->dev_uid[r];
+        c.n_devices += seen ? 0 : 1;
+        all_fine = all_fine && c.boot->fine[r] != 0;
+      }
+      if (c.n_devices > 1 && !all_fine) {
+        std::snprintf(c.why, sizeof c.why, "peer transport: %d ranks on %d devices but a mailbox is coarse-grained memory (no cross-device visibility while kernels run)",
+                      n_ranks, c.n_devices);
+        std::fprintf(stderr, "[gmg] %s\n", c.why);
+        return 1;
+      }
+    }
     for (int r = 0; r < n_ranks; ++r)
-      if (r != rank && hipIpcOpenMemHandle((void **)&c.box[r], c.boot->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) return 1;
+      if (r != rank && hipIpcOpenMemHandle((void **)&c.box[r], c.boot->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        std::snprintf(c.why, sizeof c.why, "peer transport: hipIpcOpenMemHandle of rank %d's mailbox failed", r);
+        return 1;
+      }
     c.peer = true; c.ready = true;
     return boot_barrier(c.boot, n_ranks);
   }
@@ -187,6 +234,7 @@ inline int comm_init(Comm &c, int rank, int n_ranks, const void *id_bytes) {
   memcpy(&id, id_bytes, sizeof id);
   if (ncclCommInitRank(&c.comm, n_ranks, id, rank) != ncclSuccess) return 1;
   c.rank = rank; c.n_ranks = n_ranks; c.ready = true;
+  c.n_devices = n_ranks;  // (RCCL refuses two ranks on one device)
   return 0;
 }
 
@@ -438,7 +486,16 @@ inline int allgather_chunks(Comm &c, double *full, int64_t chunk, hipStream_t st
 inline int comm_share_alloc(Comm &c, size_t bytes, char *ptrs[kPeerMaxRanks]) {
   if (!c.peer) return 1;
   for (int r = 0; r < kPeerMaxRanks; ++r) ptrs[r] = nullptr;
-  if (hipMalloc((void **)&ptrs[c.rank], bytes) != hipSuccess) return 1;
+  // the neighbours' kernels store into it (halo entries of d) while mine run: fine-grained like the mailbox; across devices
+  // nothing else is accepted
+  bool fine = false;
+  if (peer_alloc((void **)&ptrs[c.rank], bytes, &fine)) return 1;
+  c.ring_fine = fine ? 1 : 0;
+  if (c.n_devices > 1 && !fine) {
+    std::snprintf(c.why, sizeof c.why, "peer transport: shared vectors on %d devices need fine-grained memory", c.n_devices);
+    std::fprintf(stderr, "[gmg] %s\n", c.why);
+    return 1;
+  }
   if (hipMemset(ptrs[c.rank], 0, bytes) != hipSuccess) return 1;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipIpcGetMemHandle(&c.boot->shared_handle[c.rank], ptrs[c.rank]) != hipSuccess) return 1;

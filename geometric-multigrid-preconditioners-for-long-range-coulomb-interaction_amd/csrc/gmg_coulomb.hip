@@ -162,6 +162,7 @@ struct gmg_context {
   std::vector<hipEvent_t> ev_c, ev_d;  // sampled update-kernel launches
   std::vector<hipEvent_t> ev_e, ev_f;  // SSOR sweep launches
   int ev_used = 0, ev2_used = 0, ev3_used = 0;
+  long long sgs_launch_no = 0;
   hipEvent_t timed_start = nullptr, timed_stop = nullptr;  // next launch carries these as its dispatch start / stop events
   gmg_stats stats{};
   Comm comm;
@@ -601,10 +602,13 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
                 for (int32_t s2 = wp[(size_t)wv]; s2 < wp[(size_t)wv + 1] && all; ++s2) all = spat[(size_t)s2] == m.sellp_pid;
                 if (all) wp[(size_t)wv] |= kSellpFastWave;
               }
-              // Operators whose x does not fit an XCD's L2: the slices of consecutive fast waves of one XCD are dealt
-              // round-robin in pairs, so that at any time the XCD's waves sit inside a window of ~2 W slices (their x
-              // working set: three lattice planes instead of the XCD's whole eighth of x, which is then fetched once).
-              const bool rr = ctx->sellp_rr == 1 || (ctx->sellp_rr == 0 && n_rows * 8 / 8 > (int64_t)(3 << 20));
+              // Large operators: the slices of consecutive fast waves of one XCD are dealt round-robin in pairs, so that at
+              // any time the XCD's waves sit inside a window of ~2 W slices (their x working set: three lattice planes
+              // instead of the XCD's whole eighth of x, which is then fetched once).  The threshold is a MEASURED
+              // crossover in rows, not the L2 size: an XCD's eighth of x leaves its 4 MiB L2 at 4 Mi rows (8 x 4 MiB / 8 B),
+              // and below ~3 Mi rows the contiguous order was never slower (121^3 = 1.77 M rows: x/8 = 1.8 MB per XCD stays
+              // L2-resident, 17.0 us either way; 5.18 M rows: 50.7 -> 41.0 us; 201^3: PMC traffic 454 -> 197 MB).
+              const bool rr = ctx->sellp_rr == 1 || (ctx->sellp_rr == 0 && n_rows > (int64_t)(3 << 20));
               if (rr) {
                 const int per_xcd = n_waves / 8;
                 std::vector<int4> desc((size_t)n_waves, int4{0, 0, 0, -1});
@@ -831,29 +835,36 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
     p.block0 = split ? ctx->comm.rank * nbl : 0;
     if (L.sgs.w_n_coupled > 0) {
       if (ctx->sgs_profile && !L.sgs.phased) return sgs_profile_launch(ctx, L, p);
+      // sampled like the level-0 SpMV: every prof_every-th sweep launch carries start / stop events; a full pool stops
+      // the sampling (no synchronisation ever enters the timed region); stats: launches counted, samples timed
       if (ctx->prof_every > 0 && !ctx->ev_e.empty()) {
-        if (ctx->ev3_used == (int)ctx->ev_e.size()) collect_sgs_samples(ctx);  // pool full: drain it (synchronises; profiling runs only)
-        ctx->timed_start = ctx->ev_e[(size_t)ctx->ev3_used]; ctx->timed_stop = ctx->ev_f[(size_t)ctx->ev3_used++];
-        ctx->stats.sgs_substeps += L.sgs.w_steps;
-        ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
+        ctx->stats.sgs_launches++;
+        if ((ctx->sgs_launch_no++ % (ctx->prof_every | 1)) == 0 && ctx->ev3_used < (int)ctx->ev_e.size()) {  // (odd stride: a V-cycle launches 4 sweeps per level, a stride of 8 would always hit the same one)
+          ctx->timed_start = ctx->ev_e[(size_t)ctx->ev3_used]; ctx->timed_stop = ctx->ev_f[(size_t)ctx->ev3_used++];
+          ctx->stats.sgs_substeps += L.sgs.w_steps;
+          ctx->stats.sgs_stream_bytes += L.sgs.w_stream_bytes;
+        }
       }
       const size_t lds = ctx->sgs_lds_bytes_override > 0 ? (size_t)ctx->sgs_lds_bytes_override : (size_t)L.sgs.w_lds_bytes;
       if (L.sgs.phased) {
         SgsPhaseArgs q{};
         q.ranges = L.sgs.p_ranges; q.blk_tab = L.sgs.p_blk_tab; q.block_rng = p.block_rng; q.block0 = p.block0; q.stream = p.stream; q.ws_ci = p.ws_ci; q.ci_row = p.ci_row;
         q.ycur = p.ycur; q.y = p.y; q.omega = p.omega; q.y_slots = p.y_slots; q.prof = nullptr;
-        if (ctx->sgs_phase_profile > 0) {
+        if (ctx->sgs_phase_profile > 0 && n_ranks == 1) {  // (several ranks: the option is refused in gmg_set_option; the all-gather below must run)
+          // the instrumented variant of the sweep (same arithmetic, same results, s_memtime around every phase); the
+          // launch falls through to the common tail like the production one
           const size_t nr = (size_t)L.sgs.w_n_ranges;
           unsigned long long *d = nullptr;
           std::vector<unsigned long long> h(12 * nr, 0);
           HIPC(hipMalloc(&d, sizeof(unsigned long long) * 12 * nr));
-          q.prof = d; q.mode = ctx->sgs_phase_profile - 1;
+          q.prof = d;
           hipLaunchKernelGGL(sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
-          HIPC(hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream));
-          HIPC(hipStreamSynchronize(ctx->stream));
+          hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
           (void)hipFree(d);
+          if (e != hipSuccess) { ctx->err = std::string("SSOR sweep profile: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
           if (L.sgs.w_steps > 1000 && nbl == 1) {
-            std::fprintf(stderr, "[gmg] four-wave sweep, mode %d, %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", q.mode, (long long)L.n);
+            std::fprintf(stderr, "[gmg] four-wave sweep, %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", (long long)L.n);
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
               const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
@@ -862,8 +873,7 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
                            h[12 * i + 8] / turns, h[12 * i + 9] / turns);
             }
           }
-          return GMG_OK;
-        }
+        } else
         launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
       } else {
         launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
@@ -1243,6 +1253,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   std::vector<char> stream;
   int max_ws = 0;
   int64_t total_steps = 0, total_stages = 0;
+  // what the kernels take from the records as ADDRESSES: the forward sweep's global store index (aux, in doubles into the
+  // stream) and the LDS byte addresses of y slots.  Their maxima are checked against the allocation / the LDS budget
+  // before the plan is accepted (the one fault this code ever produced was a store through an aux field).
+  uint64_t max_aux = 0, max_lds_addr = 0;
   for (int b = 0; b < n_blocks; ++b) {
     const int64_t rb = block_row[(size_t)b], re = block_row[(size_t)b + 1];
     const int m = (int)(re - rb);
@@ -1541,6 +1555,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               f[0] = 0.0; f[1] = invd[(size_t)i]; f[2] = 0.0;
               wv[6] = my;
               wv[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
+              max_aux = std::max<uint64_t>(max_aux, wv[7]); max_lds_addr = std::max<uint64_t>(max_lds_addr, my);
               double *hv = f + 4, *tv = f + 4 + 8 * Gr;
               uint32_t *ha = reinterpret_cast<uint32_t *>(rec + 32 + 64 * Gr + 8 * Lr), *ta = ha + 8 * Gr;
               for (int e = 0; e < 8 * Gr; ++e) { hv[e] = 0.0; ha[e] = my; }
@@ -1554,6 +1569,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                 const int c = pcol[(size_t)k];
                 if (!in_dir(i, c)) continue;
                 const uint32_t ad = (uint32_t)slot_of[(size_t)c] * 8u;
+                max_lds_addr = std::max<uint64_t>(max_lds_addr, ad);
                 if (e < h0) { hv[e] = pval[(size_t)k]; ha[e] = ad; }
                 else if (e < h1) { tv[e - h0] = pval[(size_t)k]; ta[e - h0] = ad; }
                 else { tv[L1r + e - h1] = pval[(size_t)k]; ta[L1r + e - h1] = ad; }
@@ -1631,6 +1647,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               f[0] = 0.0; f[1] = invd[(size_t)i]; f[2] = 0.0;
               w[6] = my;
               w[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
+              max_aux = std::max<uint64_t>(max_aux, w[7]); max_lds_addr = std::max<uint64_t>(max_lds_addr, my);
               uint32_t *ad = reinterpret_cast<uint32_t *>(rec + 32 + 64 * g);
               int e = 0, seen = 0;
               for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1] && e < 8 * g; ++k) {
@@ -1638,6 +1655,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                 if (!in_dir(i, c)) continue;
                 if (seen++ < sub * w_dir) continue;  // entries of earlier sub-steps
                 f[4 + e] = pval[(size_t)k];
+                max_lds_addr = std::max<uint64_t>(max_lds_addr, (uint64_t)slot_of[(size_t)c] * 8u);
                 ad[e++] = (uint32_t)slot_of[(size_t)c] * 8u;
               }
               for (; e < 8 * g; ++e) { f[4 + e] = 0.0; ad[e] = my; }
@@ -1666,6 +1684,14 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   }
   block_rng[(size_t)n_blocks] = (int32_t)(ph ? pranges.size() : ranges.size());
   const int y_slots = std::max(2, (max_ws + 1) & ~1);
+  // ---- the plan is memory-safe by construction, and checked: every address a record carries lies inside what is allocated
+  if (!stream.empty() && (max_aux * 8 + 8 > stream.size() || max_lds_addr + 8 > (uint64_t)y_slots * 8))
+    return fail(ctx, GMG_ERR_INVALID, "SSOR plan: a record addresses memory outside the stream / the LDS slots (internal error)");
+  for (int32_t ci : ws_ci)
+    if (ci < 0 || (size_t)ci >= ci_row.size()) return fail(ctx, GMG_ERR_INVALID, "SSOR plan: working-set entry out of range (internal error)");
+  for (size_t q = 0; q < rpos_f.size(); ++q)
+    if ((uint64_t)rpos_f[q] * 8 + 8 > stream.size() || (uint64_t)rpos_b[q] * 8 + 8 > stream.size())
+      return fail(ctx, GMG_ERR_INVALID, "SSOR plan: rhs position outside the stream (internal error)");
 #define SW_UP(dst, vec, T)                                                                                          \
   HIPC(hipMalloc(&dst, sizeof(T) * std::max<size_t>((vec).size(), 1)));                                              \
   if (!(vec).empty()) HIPC(hipMemcpyAsync(dst, (vec).data(), sizeof(T) * (vec).size(), hipMemcpyHostToDevice, ctx->stream));
@@ -2341,8 +2367,23 @@ int gmg_comm_unique_id(void *out_id) { return comm_unique_id(out_id) ? GMG_ERR_C
 int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id) {
   if (!ctx || rank < 0 || n_ranks < 1 || rank >= n_ranks) return GMG_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
-  if (comm_init(ctx->comm, rank, n_ranks, id)) return fail(ctx, GMG_ERR_COMM, "ncclCommInitRank failed");
+  if (comm_init(ctx->comm, rank, n_ranks, id)) {
+    ctx->err = ctx->comm.why[0] ? std::string(ctx->comm.why) : std::string("communicator start-up failed (ncclCommInitRank / peer mailbox mapping)");
+    return GMG_ERR_COMM;
+  }
   ctx->dist = true;
+  return GMG_OK;
+}
+
+int gmg_comm_info(gmg_context *ctx, int64_t out[8]) {
+  if (!ctx || !out) return GMG_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  out[0] = ctx->dist ? ctx->comm.n_ranks : 1;
+  out[1] = !ctx->dist ? 0 : (ctx->comm.peer ? 2 : 1);
+  out[2] = ctx->comm.peer && ctx->comm.box_fine ? 1 : 0;
+  out[3] = ctx->comm.peer ? ctx->comm.ring_fine : -1;
+  out[4] = ctx->dist ? ctx->comm.n_devices : 1;
+  out[5] = l0_partitioned(ctx) ? 1 : 0;
   return GMG_OK;
 }
 
@@ -2480,13 +2521,24 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
-  else if (k == "sgs_phase_profile") ctx->sgs_phase_profile = (int)value;
+  else if (k == "sgs_phase_profile") {
+    if (on && ctx->dist && ctx->comm.n_ranks > 1) return fail(ctx, GMG_ERR_INVALID, "sgs_phase_profile: one rank only (the instrumented sweep is a single-GPU measurement)");
+    ctx->sgs_phase_profile = (int)value;
+  }
   else if (k == "sgs_phase_nosplit") ctx->sgs_phase_nosplit = on;
   else if (k == "sgs_phase_nocascade") ctx->sgs_phase_nocascade = on;
   else if (k == "sgs_phase_chunk") ctx->sgs_phase_chunk = (int)value;
   else if (k == "sgs_groups") ctx->sgs_groups = (int)value;
   else if (k == "sgs_lds_bytes_override") ctx->sgs_lds_bytes_override = (int)value;
-  else if (k == "sgs_profile") { ctx->sgs_profile = on; ctx->sgs_profile_mode = (int)value - 1; }
+  else if (k == "sgs_profile") {
+    if (on && ctx->dist && ctx->comm.n_ranks > 1) return fail(ctx, GMG_ERR_INVALID, "sgs_profile: one rank only");
+    ctx->sgs_profile = on;
+    ctx->sgs_profile_mode = (int)value - 1;
+#ifndef GMG_EXPERIMENTS
+    // the timing modes that skip work (and give wrong results) are not in this library: tools/build_experiments.sh
+    if (ctx->sgs_profile_mode > 0) return fail(ctx, GMG_ERR_UNSUPPORTED, "sgs_profile modes > 1 need a -DGMG_EXPERIMENTS build (tools/build_experiments.sh)");
+#endif
+  }
   else return fail(ctx, GMG_ERR_INVALID, "gmg_set_option: unknown key");
   return GMG_OK;
 }

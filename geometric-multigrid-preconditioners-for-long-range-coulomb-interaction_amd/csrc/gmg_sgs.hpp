@@ -41,6 +41,11 @@ constexpr int kSwMaxBlock = 8192;  // bytes of one step's records: 3 blocks + 1 
 constexpr int kSwYSlots = 15744;   // doubles of y in LDS (123 KB) by default
 constexpr uint32_t kSwSpinLimit = 1u << 22;  // polls (> 0.1 s) after which a waiting wave declares the sweep broken
 constexpr int kSwThreads = 256;    // wave 0 computes, waves 1..3 stream
+#ifdef GMG_EXPERIMENTS
+constexpr bool kSwExperiments = true;   // tools/build_experiments.sh: a library of its own, never the shipped one
+#else
+constexpr bool kSwExperiments = false;
+#endif
 
 // One range = consecutive steps of one sweep direction whose working set fits the LDS.
 struct SwRange {
@@ -98,7 +103,8 @@ struct SgsWaveArgs {
   const double *r;
   int64_t n_rows;
   int *abort_flag;           // host-visible: set when a wave of the sweep gave up waiting for its partner (results invalid)
-  int prof_mode;             // PROFILE variant, timing experiments (wrong results): 1 no chain, 2 no y gathers, 3 no a reads, 4 no next-column prefetch, 5 empty sub-step
+  int prof_mode;             // PROFILE variant in a -DGMG_EXPERIMENTS build only (timing experiments, wrong results by design): 1 no chain, 5 empty sub-step;
+                             // the shipped library compiles them out (kSwExperiments) and gmg_set_option refuses them
   unsigned long long *prof;  // PROFILE variant: per range {cycles of the sweep, of them waiting for the ring, working-set load, write-back}
 };
 
@@ -214,7 +220,7 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
     const uint32_t advance = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hdr.z);
     const uint32_t next_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.hdr.w);
     const uint32_t rec = blk + 16 + (uint32_t)min(lane, nrows - 1) * (uint32_t)sw_stride(G);
-    if (!(PROFILE && mode == 5)) {
+    if (!(PROFILE && kSwExperiments && mode == 5)) {
       // ---- every LDS read of the sub-step goes out first: y gathers, own y, values, rhs; then the next sub-step's columns
       double yv[8 * G], av[8 * G];
 #pragma unroll
@@ -237,7 +243,7 @@ __device__ __forceinline__ void sweep_range(const SwRange &R, uint32_t ring0, ui
       __builtin_amdgcn_sched_barrier(0);
       // ---- the dependent chain, in CSR order
       double acc = (flags & 1u) ? (FWD ? 0.0 : cur.prefix) : carry;
-      if (!PROFILE || mode != 1) {
+      if (!(PROFILE && kSwExperiments) || mode != 1) {
 #pragma unroll
         for (int k = 0; k < 8 * G; ++k) acc += av[k] * yv[k];
       }

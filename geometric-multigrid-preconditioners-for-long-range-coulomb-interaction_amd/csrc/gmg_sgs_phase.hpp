@@ -77,8 +77,7 @@ struct SgsPhaseArgs {
   double *ycur, *y;
   double omega;
   int y_slots;
-  unsigned long long *prof;  // per range {cycles of the phase loop, working-set load, write-back, -} (null: off)
-  int mode;                  // timing experiments (wrong results): 1 no tail chain, 2 no tail gathers, 3 no head work, 4 no record copies after the first
+  unsigned long long *prof;  // per range {cycles of the phase loop, working-set load, write-back, -} (null: off); same results either way
 };
 
 namespace ph {

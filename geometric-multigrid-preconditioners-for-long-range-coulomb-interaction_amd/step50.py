@@ -184,6 +184,13 @@ class Problem:
                                       col.ctypes.data_as(C.POINTER(C.c_int32)), val.ctypes.data_as(C.POINTER(C.c_double)))
         return SimpleNamespace(n_rows=nr.value, n_cols=nc.value, rowptr=rp, col=col[:nz.value], val=val[:nz.value], nnz=nz.value)
 
+    def matrix_shape(self, kind, level=0):
+        """(n_rows, nnz) of an operator of the current cycle without copying it."""
+        k = {"system": 0, "level": 1, "edge": 2, "prolongation": 3}[kind]
+        nr, nc, nz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.step50_matrix_shape(self.h, C.c_int(k), C.c_int(level), C.byref(nr), C.byref(nc), C.byref(nz)), "matrix_shape")
+        return int(nr.value), int(nz.value)
+
     def copy_indices(self, level):
         n = self.L.step50_copy_indices_size(self.h, C.c_int(level))
         g, l = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)

@@ -151,6 +151,12 @@ int gmg_comm_init(gmg_context *ctx, int rank, int n_ranks, const void *id);
 /* The ranks meet on the host (call it when the operators are set, before the solve: the ranks' host-side setup times
  * differ by seconds, the kernels of the peer transport wait for each other by polling).  No-op without a communicator. */
 int gmg_comm_barrier(gmg_context *ctx);
+/* What the communicator turned out to be (bench.py records it): out[0] ranks, out[1] transport (0 none, 1 RCCL,
+ * 2 peer-to-peer stores), out[2] peer mailbox in fine-grained memory (0 / 1), out[3] shared direction ring of the
+ * coarse CG (-1 not allocated, 0 plain hipMalloc, 1 fine-grained), out[4] distinct GPUs under the ranks, out[5]
+ * level 0 row-partitioned (0 / 1), out[6..7] reserved (0).  Stands where the reference would print
+ * Utilities::MPI::n_mpi_processes (src/step-50.cc:120-122).                                                      */
+int gmg_comm_info(gmg_context *ctx, int64_t out[8]);
 /* Distributed layout: the system matrix / outer-CG vectors and level 0 (matrix,
  * coarse CG) are row-partitioned in equal chunks -- gmg_partition_range gives the canonical
  * owned range, mirroring locally_owned_dofs() of the reference (:656-657) -- while levels >= 1,
@@ -190,10 +196,12 @@ typedef struct gmg_stats {
   double sgs_ms_total;          /* their summed event time                                                           */
   int64_t sgs_substeps;         /* dependent steps those launches walked (the sweep is latency bound)                */
   int64_t sgs_stream_bytes;     /* record bytes they streamed                                                        */
+  int64_t sgs_launches;         /* all SSOR sweep launches while profiling was on (every sample_every-th one is timed)  */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);
-/* attach HIP start / stop events to every `sample_every`-th level-0 SpMV launch (0 = off).  */
+/* attach HIP start / stop events to every `sample_every`-th level-0 SpMV launch and every `sample_every`-th SSOR
+ * sweep launch (0 = off); when the event pool is full the sampling stops, nothing ever synchronises.        */
 int gmg_set_profiling(gmg_context *ctx, int sample_every);
 /* streaming-read and copy bandwidth of this device (GB/s) on n_bytes per array: the measured
  * ceiling bench.py prints beside the 8 TB/s spec peak.                                    */
@@ -205,7 +213,9 @@ int gmg_set_tuning(gmg_context *ctx, int coarse_chunk, int cg_variant);
 /* Diagnostic / measurement options by name (defaults are the production paths).  Keys: host_threads,
  * debug_upload, disable_sell, disable_patterns, disable_compression, disable_sellp, disable_rowclass, sell_grid, sellp_cost,
  * cg_variant, coarse_chunk, sgs_y_slots (doubles of LDS the SSOR sweep may use for y: small values force
- * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep), sgs_profile (instrumented sweep),
+ * several LDS ranges), sgs_disable_wave (SSOR through the generic CSR sweep), sgs_disable_phase (the one-wave sweep),
+ * sgs_phase_profile (cycle counters of the four-wave sweep: same results, one rank only), sgs_profile (instrumented
+ * one-wave sweep; its wrong-result timing modes exist only in a -DGMG_EXPERIMENTS build, tools/build_experiments.sh),
  * sgs_lds_bytes_override (tests: a value over the CU's 160 KB makes the sweep's launch fail -> GMG_ERR_HIP).  Options that shape a device
  * layout take effect at the next gmg_set_*_matrix.  The same keys are read once from the environment
  * variable GMG_OPTIONS="key=value,..." at gmg_create (for profiling scripts around bench.py).        */

@@ -1,9 +1,12 @@
 """Two ranks on ONE GPU: the rank-parallel layout end to end.
 
-RCCL refuses two ranks on the same device, so the ranks talk through the library's host-staged
-shared-memory transport (GMG_COMM_TRANSPORT=peer, csrc/gmg_comm.hpp) -- same partition, same halo
-plans, same pack / unpack kernels, same distributed coarse CG and V-cycle all-gathers as over
-RCCL; only the bytes travel differently.  Checked against the reference's printed numbers (the
+RCCL refuses two ranks on the same device, so the ranks talk through the library's peer-to-peer
+transport (GMG_COMM_TRANSPORT=peer, csrc/gmg_comm.hpp: hipIpc-mapped mailboxes, the sender's kernel
+stores into the receiver's memory and publishes a sequence number, the receiver's kernel polls it;
+the coarse CG pushes the halo entries of d into the neighbours' shared direction vectors) -- same
+partition, same halo plans, same distributed coarse CG and V-cycle all-gathers as over RCCL; only
+the bytes travel differently.  On this one-GPU box the "peer" stores land in the same device; what
+anchors the N-rank results are the reference's logs and the single-process layout.  Checked against the reference's printed numbers (the
 reductions are summed in a different order than on one rank, hence 1e-9 instead of 11 digits
 for the norms; the iteration counts must not change -- the reference's mpirun=3 / mpirun=7 logs
 show the same counts as mpirun=1)."""

@@ -9,7 +9,8 @@ mkdir -p $R/gpurun_out/pmc_traffic
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 cd /tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-smoother-table --steps 1 --warmup 0 --profile-every 0 --cycles ${CYCLES:-1} --workload $W"
-COMMIT=$(cat $R/.bench_commit 2>/dev/null || echo unknown)
+COMMIT=$(cut -d" " -f1 $R/.bench_commit 2>/dev/null || echo unknown)
+SRC=$(python3 $R/bench.py --source-hash)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_traffic/$c  # a pass of another workload must not leak into this one
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_traffic/$c -- $B > $R/gpurun_out/pmc_traffic/$c.log 2>&1 || { echo "$c failed"; exit 1; }
@@ -33,6 +34,6 @@ for k, v in agg.items():
     # counters are in KB; gfx950 FETCH_SIZE counts 64 B per 128-B request of wide streaming reads -> x2
     out[name] = {"fetch_kb": med["FETCH_SIZE"], "write_kb": med["WRITE_SIZE"], "launches": len(v["FETCH_SIZE"]),
                  "traffic_bytes": int((2 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024)}
-json.dump({"$W": {"commit": "$COMMIT", "cycles": ${CYCLES:-1}, "kernels": out}}, open("$R/gpurun_out/pmc_traffic_$W.json", "w"), indent=1)
+json.dump({"$W": {"commit": "$COMMIT", "source_sha16": "$SRC", "cycles": ${CYCLES:-1}, "kernels": out}}, open("$R/gpurun_out/pmc_traffic_$W.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
