@@ -10,6 +10,7 @@
 #include "gmg_device.hpp"
 #include "gmg_sgs.hpp"
 #include "gmg_sgs_phase.hpp"
+#include "gmg_lattice.hpp"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -60,6 +61,15 @@ struct DevCSR {
   bool val8 = false, col16 = false;
   int n_slices = 0, sell_grid = 0;
   int64_t sell_quads = 0;
+  // lattice interior walked plane by plane (gmg_lattice.hpp): rows [lat_R0, lat_R1) by class table, the other slices from the SELL streams
+  bool lattice = false;
+  uint8_t *lat_rowcls = nullptr;
+  double *lat_ctab = nullptr;
+  int32_t *lat_gen = nullptr;
+  int lat_W = 0;               // rows of the window that repeats with the plane stride (== lat_nxy: one contiguous interior)
+  int64_t lat_fast_rows = 0;
+  int lat_classes = 0, lat_nx = 0, lat_nxy = 0, lat_R0 = 0, lat_R1 = 0, lat_C = 0, lat_K = 0, lat_S = 0, lat_fast_blocks = 0, lat_n_gen = 0, lat_grid = 0;
+  int64_t lat_gen_bytes = 0;  // stream bytes of the slices outside the interior
 };
 
 struct SgsPlan {
@@ -150,7 +160,8 @@ struct gmg_context {
   int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the four-wave sweep
   int sgs_groups = 0;  // 0: chosen per sweep direction; 1..4: forced (experiments)
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
-  bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false;
+  bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false, disable_lattice = false;
+  int lattice_segments = 0;  // segments per XCD slab of the lattice kernel (0: by size)
   int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
   int sellp_rr = 0;         // round-robin slice order of the fast waves: 0 by size, 1 on, 2 off
   double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
@@ -240,6 +251,9 @@ void free_csr(DevCSR &m) {
   if (m.sellp_wave_rr) (void)hipFree(m.sellp_wave_rr);
   if (m.sellp_rowcls) (void)hipFree(m.sellp_rowcls);
   if (m.sellp_ctab) (void)hipFree(m.sellp_ctab);
+  if (m.lat_rowcls) (void)hipFree(m.lat_rowcls);
+  if (m.lat_ctab) (void)hipFree(m.lat_ctab);
+  if (m.lat_gen) (void)hipFree(m.lat_gen);
   if (m.slice_base) (void)hipFree(m.slice_base);
   if (m.sell_vals) (void)hipFree(m.sell_vals);
   if (m.sell_cols) (void)hipFree(m.sell_cols);
@@ -270,6 +284,9 @@ void parallel_chunks(int64_t n, F f) {
   }
   for (auto &x : th) x.join();
 }
+
+// the lattice interior only needs the rows whose columns are owned (< n_rows): any n_cols >= n_rows qualifies
+inline int64_t n_cols_owned(int64_t n_rows, int64_t n_cols) { return n_cols >= n_rows ? n_rows : -1; }
 
 int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, const int64_t *rowptr, const int32_t *col,
                const double *val, bool keep_csr = false) {
@@ -641,6 +658,161 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
           HIPC(hipStreamSynchronize(ctx->stream));
         }
       }
+      // ---- lattice interior (gmg_lattice.hpp): the nine runs are the (dz, dy) lines of an nx x ny x nz vertex lattice
+      // numbered lexicographically -> the rows whose columns are all owned lattice neighbours are walked plane by plane
+      // from a class table; everything else stays on the SELL streams.
+      if (val8 && !ctx->disable_lattice && m.sellp_pid >= 0 && n_rows == n_cols_owned(n_rows, n_cols) && n_rows < ((int64_t)1 << 28)) {
+        const int64_t nx = m.sellp_centre[5] - m.sellp_centre[4], nxy = m.sellp_centre[7] - m.sellp_centre[4];
+        bool lat_ok = nx >= 3 && nxy >= 3 * nx;
+        for (int u = 0; u < 9 && lat_ok; ++u) lat_ok = m.sellp_centre[u] == (u / 3 - 1) * nxy + (u % 3 - 1) * nx;
+        const int64_t reach = nxy + nx + 1;
+        if (lat_ok && n_rows > 4 * reach + 256) {
+          // per row: are all stored columns owned lattice neighbours (27 offsets), and is every offset in range?
+          std::vector<char> row_ok((size_t)n_rows, 0);
+          parallel_chunks(n_rows, [&](int64_t rb2, int64_t re2, int) {
+            for (int64_t r2 = rb2; r2 < re2; ++r2) {
+              // (lane 0 of a unit holds the two rows in front of the unit's first row: their lowest neighbour is row - 2 - reach;
+              // the highest index read is n_rows + 1: every vector has two spare entries)
+              bool ok = r2 >= reach + 2 && r2 + reach < n_rows;
+              for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1] && ok; ++k) {
+                const int64_t t = (int64_t)col[k] - r2 + reach;
+                ok = col[k] < n_rows && t >= 0 && t / nxy <= 2 && (t % nxy) / nx <= 2 && (t % nxy) % nx <= 2;
+              }
+              row_ok[(size_t)r2] = ok ? 1 : 0;
+            }
+          });
+          // longest run of good rows.  A lexicographic numbering gives one run over the whole interior; deal.II's
+          // cell-by-cell numbering (the host side's) breaks it at every plane: the first three lines of a plane (and the
+          // first three planes) are numbered in first-touch order.  So the interior is a WINDOW of W rows that repeats with
+          // the plane stride: rows R0 + k nxy + [0, W), k < K.
+          int64_t best_b = 0, best_e = 0, cur_b = -1;
+          for (int64_t r2 = 0; r2 <= n_rows; ++r2) {
+            const bool ok = r2 < n_rows && row_ok[(size_t)r2];
+            if (ok && cur_b < 0) cur_b = r2;
+            if (!ok && cur_b >= 0) {
+              if (r2 - cur_b > best_e - best_b) { best_b = cur_b; best_e = r2; }
+              cur_b = -1;
+            }
+          }
+          int64_t R0 = best_b, R1 = best_e, Wd = std::min<int64_t>(best_e - best_b, nxy), Kp = 0;
+          if (best_e - best_b >= nxy) {
+            Kp = (best_e - best_b + nxy - 1) / nxy;  // the last plane step may be cut by R1
+          } else if (Wd > 0) {
+            std::vector<int32_t> bad_before((size_t)n_rows + 1, 0);  // prefix count of bad rows
+            for (int64_t r2 = 0; r2 < n_rows; ++r2) bad_before[(size_t)r2 + 1] = bad_before[(size_t)r2] + (row_ok[(size_t)r2] ? 0 : 1);
+            auto window_ok = [&](int64_t b2) { return b2 >= 0 && b2 + Wd <= n_rows && bad_before[(size_t)(b2 + Wd)] == bad_before[(size_t)b2]; };
+            int64_t lo = best_b, hi = best_b;
+            while (window_ok(lo - nxy)) lo -= nxy;
+            while (window_ok(hi + nxy)) hi += nxy;
+            R0 = lo; Kp = (hi - lo) / nxy + 1; R1 = hi + Wd;
+          }
+          const int64_t n_fast = Wd == nxy ? R1 - R0 : Kp * Wd;
+          if (ctx->debug_upload)
+            std::fprintf(stderr, "[gmg]   lattice rows: longest run [%lld, %lld) -> window of %lld rows x %lld planes from row %lld: %lld of %lld rows\n", (long long)best_b, (long long)best_e,
+                         (long long)Wd, (long long)Kp, (long long)R0, (long long)n_fast, (long long)n_rows);
+          auto is_fast = [&](int64_t r2) { return r2 >= R0 && r2 < R1 && (r2 - R0) % nxy < Wd; };
+          // what the marching waves read: rows R0 - 2 - reach .. R1 + 1 + reach - 1 of x (lane 0 / lane 63 of a unit sit two
+          // rows outside it): checked here, once, instead of trusting the row test above
+          const bool reads_inside = R0 - 2 - reach >= 0 && R1 + reach <= n_rows;
+          if (n_fast >= n_rows / 2 && Wd >= 2 && reads_inside) {
+            // classes: the 27 value codes of a row by offset position (0 = +0.0 where the row stores nothing)
+            std::vector<uint8_t> rowcls((size_t)n_rows, 0);
+            const int nt = host_threads();
+            std::vector<std::map<std::array<uint8_t, 27>, int>> local_cls((size_t)nt);
+            std::vector<std::vector<std::array<uint8_t, 27>>> local_keys((size_t)nt);
+            std::vector<std::array<int64_t, 2>> local_rng((size_t)nt, {0, 0});
+            std::vector<std::vector<int32_t>> local_id((size_t)nt);
+            parallel_chunks(R1 - R0, [&](int64_t cb, int64_t ce, int t) {
+              auto &M = local_cls[(size_t)t];
+              local_rng[(size_t)t] = {R0 + cb, R0 + ce};
+              local_id[(size_t)t].resize((size_t)(ce - cb));
+              for (int64_t r2 = R0 + cb; r2 < R0 + ce; ++r2) {
+                std::array<uint8_t, 27> key;
+                key.fill(0);
+                if (!is_fast(r2)) { local_id[(size_t)t][(size_t)(r2 - R0 - cb)] = -1; continue; }
+                for (int64_t k = rowptr[r2]; k < rowptr[r2 + 1]; ++k) {
+                  const int64_t t2 = (int64_t)col[k] - r2 + reach;
+                  const int pos = (int)((t2 / nxy) * 9 + ((t2 % nxy) / nx) * 3 + (t2 % nxy) % nx);
+                  uint64_t bits;
+                  std::memcpy(&bits, &val[k], 8);
+                  key[(size_t)pos] = code_lookup(bits);
+                }
+                auto ins = M.emplace(key, (int)M.size());
+                if (ins.second) local_keys[(size_t)t].push_back(key);
+                local_id[(size_t)t][(size_t)(r2 - R0 - cb)] = ins.first->second;
+              }
+            });
+            std::map<std::array<uint8_t, 27>, int> cls_of;
+            std::vector<double> ctab;
+            bool cls_ok = true;
+            for (int t = 0; t < nt && cls_ok; ++t) {
+              std::vector<int> remap(local_keys[(size_t)t].size(), 0);
+              for (size_t q = 0; q < local_keys[(size_t)t].size() && cls_ok; ++q) {
+                auto ins = cls_of.emplace(local_keys[(size_t)t][q], (int)cls_of.size());
+                if (ins.second) {
+                  if ((int)cls_of.size() > kLatMaxClasses) { cls_ok = false; m.lat_classes = -(int)cls_of.size(); break; }
+                  for (int j = 0; j < 27; ++j) ctab.push_back(dict[local_keys[(size_t)t][q][(size_t)j]]);
+                }
+                remap[q] = ins.first->second;
+              }
+              if (!cls_ok) break;
+              for (int64_t r2 = local_rng[(size_t)t][0]; r2 < local_rng[(size_t)t][1]; ++r2) {
+                const int32_t id = local_id[(size_t)t][(size_t)(r2 - local_rng[(size_t)t][0])];
+                if (id >= 0) rowcls[(size_t)r2] = (uint8_t)remap[(size_t)id];
+              }
+            }
+            if (cls_ok && !cls_of.empty()) {
+              std::vector<int32_t> gen;
+              int64_t gen_bytes = 0;
+              for (int64_t sl = 0; sl < n_slices; ++sl) {
+                bool all_fast = true;  // a slice with any row outside the interior is served from the streams (its interior rows masked)
+                for (int64_t r2 = sl * 64; r2 < std::min<int64_t>(n_rows, sl * 64 + 64) && all_fast; ++r2) all_fast = is_fast(r2);
+                if (!all_fast) {
+                  gen.push_back((int32_t)sl);
+                  gen_bytes += (int64_t)(sp[(size_t)sl + 1] - sp[(size_t)sl]) * 256 * (1 + (spat[(size_t)sl] >= 0 ? 0 : (col16 ? 2 : 4))) + 8;
+                }
+              }
+              m.lat_nx = (int)nx; m.lat_nxy = (int)nxy; m.lat_R0 = (int)R0; m.lat_R1 = (int)R1; m.lat_W = (int)Wd;
+              m.lat_C = (int)((Wd + kLatRowsPerUnit - 1) / kLatRowsPerUnit);
+              m.lat_K = (int)Kp;
+              m.lat_fast_rows = n_fast;
+              // segments per XCD slab: 2.5 - 3 marching waves per SIMD (measured at 121^3: 2 segments 13.0 us, 3 segments 11.8 us
+              // on a pure lattice) as long as a wave keeps >= 4 steps; the register budget admits four waves per SIMD = 1024
+              // workgroups: what the marching waves leave free goes to the slices outside the interior
+              const int slab = std::max(1, m.lat_K / 8);
+              int S = (int)std::max<int64_t>(1, (2816 / 8 + m.lat_C / 2) / m.lat_C);
+              S = std::min(S, std::max(1, slab / 4));
+              if (ctx->lattice_segments > 0) S = std::min(ctx->lattice_segments, slab);
+              m.lat_S = S;
+              m.lat_fast_blocks = 8 * ((S * m.lat_C + 3) / 4);
+              // the slices outside the interior: per-entry gathers, ~10 x the cost of an interior row; one slice per wave if
+              // the launch stays resident at once
+              const int gen_blocks = gen.empty() ? 0 : (int)std::min<size_t>((size_t)std::max(64, 256 * kLatWavesPerSimd - m.lat_fast_blocks), (gen.size() + 3) / 4);
+              m.lat_grid = m.lat_fast_blocks + gen_blocks;
+              m.lat_n_gen = (int)gen.size();
+              m.lat_gen_bytes = gen_bytes;
+              m.lat_classes = (int)cls_of.size();
+              if (m.lat_grid <= kMaxPartials) {
+                HIPC(hipMalloc(&m.lat_rowcls, rowcls.size() + 64));
+                HIPC(hipMalloc(&m.lat_ctab, sizeof(double) * ctab.size()));
+                HIPC(hipMalloc(&m.lat_gen, sizeof(int32_t) * std::max<size_t>(gen.size(), 1)));
+                HIPC(hipMemcpyAsync(m.lat_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice, ctx->stream));
+                HIPC(hipMemcpyAsync(m.lat_ctab, ctab.data(), sizeof(double) * ctab.size(), hipMemcpyHostToDevice, ctx->stream));
+                if (!gen.empty()) HIPC(hipMemcpyAsync(m.lat_gen, gen.data(), sizeof(int32_t) * gen.size(), hipMemcpyHostToDevice, ctx->stream));
+                HIPC(hipStreamSynchronize(ctx->stream));
+                m.lattice = true;
+                if (ctx->debug_upload)
+                  std::fprintf(stderr, "[gmg]   lattice interior: nx %d nxy %d rows [%d, %d) of %lld, %d classes, %d columns x %d steps, %d segments per XCD slab, grid %d + %d, %d slices outside\n",
+                               m.lat_nx, m.lat_nxy, m.lat_R0, m.lat_R1, (long long)n_rows, m.lat_classes, m.lat_C, m.lat_K, m.lat_S, m.lat_fast_blocks, gen_blocks, m.lat_n_gen);
+              }
+            }
+          }
+        }
+        if (ctx->debug_upload && !m.lattice)
+          std::fprintf(stderr, "[gmg]   lattice interior not used: nx %lld nxy %lld lattice-shaped %d rows %lld reach %lld classes %d\n", (long long)nx, (long long)nxy, (int)lat_ok,
+                       (long long)n_rows, (long long)reach, m.lat_classes);
+        phase("lattice plan");
+      }
       if (!keep_csr) {  // the CSR copy is only kept where the SGS sweeps need it (levels >= 1)
         (void)hipFree(m.col); (void)hipFree(m.val); (void)hipFree(m.tile_row);
         m.col = nullptr; m.val = nullptr; m.tile_row = nullptr;
@@ -702,6 +874,17 @@ template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
   if (m.sell) {
     SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
+    if constexpr (MODE == kStore && (CG == 0 || CG == 2)) {
+      if (m.lattice && !a.init) {
+        LatArgs la{};
+        la.pa.sa = sa; la.pa.col16 = m.col16 ? 1 : 0;
+        la.rowcls = m.lat_rowcls; la.ctab = m.lat_ctab; la.n_classes = m.lat_classes;
+        la.nx = m.lat_nx; la.nxy = m.lat_nxy; la.W = m.lat_W; la.R0 = m.lat_R0; la.R1 = m.lat_R1; la.C = m.lat_C; la.K = m.lat_K; la.S = m.lat_S;
+        la.fast_blocks = m.lat_fast_blocks; la.gen_slices = m.lat_gen; la.n_gen = m.lat_n_gen;
+        launch_timed(ctx, spmv_lattice_kernel<CG>, dim3(m.lat_grid), dim3(kThreads), 0, la);
+        return m.lat_grid;
+      }
+    }
     if (m.use_sellp) {
       SellPatArgs pa{};
       pa.sa = sa; pa.wave_ptr = m.sellp_wave_ptr; pa.wave_rr = m.sellp_wave_rr; pa.pid0 = m.sellp_pid; pa.col16 = m.col16 ? 1 : 0;
@@ -1982,6 +2165,10 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
       const int64_t val_bytes = L.A.rowclass ? (int64_t)(frac_stream * (double)ent) + (int64_t)L.A.n_pattern_slices * 64 : ent * (L.A.val8 ? 1 : 8);
       ctx->stats.spmv0_matrix_bytes = val_bytes + (int64_t)(frac_stream * (double)ent * (L.A.col16 ? 2 : 4)) + 8 * (int64_t)L.A.n_slices;
       if (L.A.rowclass) ctx->stats.spmv0_layout += 16;
+      if (L.A.lattice) {  // one class byte per interior row + the streams of the slices outside
+        ctx->stats.spmv0_layout += 32;
+        ctx->stats.spmv0_matrix_bytes = L.A.lat_fast_rows + L.A.lat_gen_bytes;
+      }
     } else {
       ctx->stats.spmv0_matrix_bytes = 12 * rowptr[n_rows] + 4 * (n_rows + 1);
     }
@@ -2513,6 +2700,8 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "disable_compression") ctx->disable_compression = on;
   else if (k == "disable_sellp") ctx->disable_sellp = on;
   else if (k == "disable_rowclass") ctx->disable_rowclass = on;
+  else if (k == "disable_lattice") ctx->disable_lattice = on;
+  else if (k == "lattice_segments") ctx->lattice_segments = (int)value;
   else if (k == "sell_grid") ctx->sell_grid = (int)value;
   else if (k == "sellp_cost") ctx->sellp_cost = value;
   else if (k == "sellp_rr") ctx->sellp_rr = (int)value;

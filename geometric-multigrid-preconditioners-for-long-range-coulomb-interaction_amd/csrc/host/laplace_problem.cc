@@ -206,7 +206,10 @@ void ParameterReader::declare_parameters() {
             {"Partition level 0", "auto"},
             // HEAD marks with Kelly + the cell residual (:1040-1089); the cluster logs (January 2018) are reproduced by
             // the Kelly indicator alone (tools/marking_rule_scan.py)
-            {"Refinement estimator", "Kelly + residual"}};
+            {"Refinement estimator", "Kelly + residual"},
+            // level 0 is the undivided lattice: numbered lexicographically (x fastest) its operator is a pure 27-point
+            // stencil for the device's plane-by-plane kernel; "cell-wise" = deal.II's first-touch order on level 0 as well
+            {"Level 0 numbering", "lexicographic"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -272,6 +275,9 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.refinement_estimator = prm.get("Refinement estimator");
   if (p.refinement_estimator != "Kelly + residual" && p.refinement_estimator != "Kelly")
     throw std::runtime_error("Refinement estimator must be <Kelly + residual> or <Kelly>");
+  p.level0_numbering = prm.get("Level 0 numbering");
+  if (p.level0_numbering != "lexicographic" && p.level0_numbering != "cell-wise")
+    throw std::runtime_error("Level 0 numbering must be <lexicographic> or <cell-wise>");
   return p;
 }
 
@@ -545,6 +551,15 @@ void LaplaceProblem<dim>::distribute_dofs() {
         const uint64_t key = triangulation.vertex_key(l, cell, a);
         if (map.emplace(key, (int32_t)vec.size()).second) vec.push_back(key);
       }
+    if (l == 0 && par.level0_numbering == "lexicographic") {
+      // Level 0 is the undivided lattice (subdivided_hyper_rectangle, src/step-50.cc:1526) and carries no smoother: its
+      // numbering only permutes rows / columns of A_0, P_0 and the copy indices (results change in the last bits of a few
+      // sums).  Vertex keys order by (z, y, x): ascending keys = lexicographic DoFs, and A_0 becomes a pure 27-point stencil
+      // with strides 1, nx, nx ny -- what the device's plane-by-plane kernel (csrc/gmg_lattice.hpp) wants.  deal.II's real
+      // level numbering on the reference's p4est partition is not reproducible here either way.
+      std::sort(vec.begin(), vec.end());
+      for (size_t i = 0; i < vec.size(); ++i) map[vec[i]] = (int32_t)i;
+    }
   }
 }
 

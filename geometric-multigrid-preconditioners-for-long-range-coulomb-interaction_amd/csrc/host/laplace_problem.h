@@ -65,6 +65,7 @@ struct Parameters {
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
   std::string refinement_estimator = "Kelly + residual";  // HEAD (:1040-1089) | "Kelly": the indicator of the older cluster runs
+  std::string level0_numbering = "lexicographic";  // lexicographic | cell-wise (deal.II's first-touch order): level 0 carries no smoother
   static Parameters from(const ParameterReader &prm);
 };
 

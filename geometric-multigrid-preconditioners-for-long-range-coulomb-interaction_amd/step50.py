@@ -77,6 +77,7 @@ def prm_text(**kw) -> str:
         "densities_on_device": ("Misc", "Charge densities on device"),
         "partition_level0": ("Solver input data", "Partition level 0"),
         "refinement_estimator": ("Misc", "Refinement estimator"),
+        "level0_numbering": ("Misc", "Level 0 numbering"),
     }
     sections = {}
     for k, v in kw.items():

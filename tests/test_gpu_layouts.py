@@ -53,7 +53,7 @@ def banded(n, width, rng, distinct=None, spread=1, n_classes=0):
 
 
 @pytest.mark.parametrize("case,expect", [
-    ("val8_col16_runs", 1 + 2 + 4 + 8), ("val8_col16_rowclass", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_rr", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_codes", 1 + 2 + 4 + 8), ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
+    ("val8_col16_runs", 1 + 2 + 4 + 8), ("val8_col16_lattice", 1 + 2 + 4 + 8 + 16 + 32), ("val8_col16_rowclass", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_rr", 1 + 2 + 4 + 8 + 16), ("val8_col16_rowclass_codes", 1 + 2 + 4 + 8), ("val8_col16", 1 + 2 + 4), ("val64_col16", 1 + 4), ("val8_col32", 1 + 2), ("val64_col32", 1),
 ])
 def test_sell_variants_bit_exact(case, expect):
     """27 consecutive columns per row are nine runs of three: with 8-bit value codes that operator goes to
@@ -61,14 +61,19 @@ def test_sell_variants_bit_exact(case, expect):
     have few distinct coefficient vectors (a lattice: here 7 of them) the kernel runs with row classes (bit 16: one
     class byte per row instead of one code per entry) unless those are switched off; random values per entry give far
     more than 96 classes and stay on the codes.  `_rr`: the round-robin slice order large lattices get (here forced; a
-    bigger operator so that every wave owns several pairs of slices)."""
+    bigger operator so that every wave owns several pairs of slices).  `_lattice`: nine runs of three with strides 3 and 9
+    ARE a 3 x 3 x n lattice in the kernel's terms: with few classes the plane-by-plane kernel (bit 32) takes the interior rows;
+    the other row-class cases switch it off to stay on the kernel they were written for."""
     rng = np.random.default_rng(11)
     n = (5000 if not case.endswith("_rr") else 700000) + 37  # not a multiple of 64
     distinct = np.array([-1 / 6, -1 / 12, 8 / 3, 0.0, 1.25]) if "val8" in case else None
     spread = 1 if "col16" in case else 3000  # 27 * 3000 > 65535 columns within a slice
-    m = banded(n if spread == 1 else 200000, 27, rng, distinct, spread, n_classes=7 if "rowclass" in case else 0)
+    m = banded(n if spread == 1 else 200000, 27, rng, distinct, spread, n_classes=7 if ("rowclass" in case or "lattice" in case) else 0)
     x = rng.standard_normal(m.n_cols)
-    y, lay = apply_level0(m, x, ("disable_sellp",) if case == "val8_col16" else ("disable_rowclass",) if case.endswith("_codes") else ("sellp_rr",) if case.endswith("_rr") else ())
+    opts = ("disable_sellp",) if case == "val8_col16" else ("disable_rowclass",) if case.endswith("_codes") else ("sellp_rr",) if case.endswith("_rr") else ()
+    if "rowclass" in case:
+        opts += ("disable_lattice",)
+    y, lay = apply_level0(m, x, opts)
     assert lay == expect, (case, lay)
     assert np.array_equal(y, go.spmv(m, x))
 
@@ -279,8 +284,8 @@ def test_full_size_operator_properties(full_size):
         scale = np.abs(A_a).max() + np.abs(A_b).max()
         assert np.abs(A_ab - (2.0 * A_a - 3.0 * A_b)).max() <= 1e-13 * scale * 10          # linearity
         assert abs(ctx.dot(vb, ya) - ctx.dot(va, yb)) <= 1e-11 * abs(ctx.dot(va, ya))        # symmetry
-    # the 121^3 level-0 product (pattern-run kernel, layout bit 8) against the oracle, bit for bit
-    assert (int(ctx.stats().spmv0_layout) - 1) & 8
+    # the 121^3 level-0 product (plane-by-plane lattice kernel, layout bit 32) against the oracle, bit for bit
+    assert (int(ctx.stats().spmv0_layout) - 1) & 32
     A0 = p.matrix("level", 0)
     ctx.spmv(0, ya, va)
     assert np.array_equal(ya.download(), go.spmv(A0, a))

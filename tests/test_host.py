@@ -85,10 +85,21 @@ def test_host_assembly_equals_oracle_generator_8_atoms(golden_dir):
     assert np.abs(b - oh.system_rhs).max() <= 1e-13 * np.abs(oh.system_rhs).max()
     assert hh.system_matrix.nnz == (3 * 45 - 2) ** 3
     _perm_compare(hh.system_matrix, oh.system_matrix, perm)
-    _perm_compare(hh.level_matrices[0], oh.level_matrices[0], perm)
+    # level 0 is numbered lexicographically ("Level 0 numbering", default): the oracle generator's order, entry for entry
+    _perm_compare(hh.level_matrices[0], oh.level_matrices[0], np.arange(91125))
+    lv = hh.level_matrices[0]
+    assert np.array_equal(lv.rowptr, oh.level_matrices[0].rowptr) and np.array_equal(lv.col, oh.level_matrices[0].col)
     cm = np.zeros(91125, dtype=bool)
     cm[perm] = hh.constrained
     assert np.array_equal(cm, oh.constrained)
+    # "cell-wise": deal.II's first-touch order on level 0 as well -- then level 0 and the active mesh (identical at cycle 0)
+    # share one numbering
+    p2 = Sm.Problem(Sm.prm_text(left=0, right=1, mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3,
+                                bc="Inhomogeneous", cycles=1, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1,
+                                global_refinement=0, level0_numbering="cell-wise"))
+    p2.read_lammps(os.path.join(golden_dir, "atom_n1_8.data"))
+    p2.run_cycle(0, on_device=False)
+    _perm_compare(p2.matrix("level", 0), oh.level_matrices[0], perm)
 
 
 @pytest.mark.parametrize("dim,key", [(2, "tests_2D/step-16.mpirun=1"), (3, "tests_3D/step-16.mpirun=1")])
