@@ -10,6 +10,9 @@
 #include "gmg_device.hpp"
 #include "gmg_sgs.hpp"
 #include "gmg_sgs_phase.hpp"
+#ifdef GMG_EXPERIMENTS
+#include "gmg_sgs_chain.hpp"  // hand-over through an LDS word instead of s_barrier: measured slower, kept as an experiment
+#endif
 #include "gmg_lattice.hpp"
 #include <hip/hip_ext.h>
 
@@ -152,7 +155,7 @@ struct gmg_context {
   int coarse_chunk = 0;
   // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
-  bool sgs_disable_wave = false, sgs_disable_phase = false, debug_upload = false, sgs_profile = false;
+  bool sgs_disable_wave = false, sgs_disable_phase = false, sgs_chain = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
   int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
   bool sgs_phase_nocascade = false;  // every step gathers all T1 slots of its shape (comparison)
@@ -1041,22 +1044,30 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
           std::vector<unsigned long long> h(12 * nr, 0);
           HIPC(hipMalloc(&d, sizeof(unsigned long long) * 12 * nr));
           q.prof = d;
+#ifdef GMG_EXPERIMENTS
+          if (ctx->sgs_chain) hipLaunchKernelGGL(sgs_chain_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q, ctx->sgs_abort);
+          else
+#endif
           hipLaunchKernelGGL(sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
           hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream);
           if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
           (void)hipFree(d);
           if (e != hipSuccess) { ctx->err = std::string("SSOR sweep profile: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
           if (L.sgs.w_steps > 1000 && nbl == 1) {
-            std::fprintf(stderr, "[gmg] four-wave sweep, %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", (long long)L.n);
+            std::fprintf(stderr, "[gmg] four-wave sweep (%s), %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", ctx->sgs_chain ? "hand-over through an LDS word" : "s_barrier per phase", (long long)L.n);
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
               const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
-              std::fprintf(stderr, "[gmg]   %s steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers %.0f\n", P.backward ? "bwd" : "fwd", P.n_steps,
+              std::fprintf(stderr, "[gmg]   %s steps %4d | %7.1f | %llu | wave 0 per turn: wait %.0f reads %.0f copy %.0f P2 %.0f CRIT %.0f barriers / polls %.0f\n", P.backward ? "bwd" : "fwd", P.n_steps,
                            (double)h[12 * i] / std::max(1, P.n_steps), h[12 * i + 2] + h[12 * i + 3], h[12 * i + 4] / turns, h[12 * i + 5] / turns, h[12 * i + 6] / turns, h[12 * i + 7] / turns,
                            h[12 * i + 8] / turns, h[12 * i + 9] / turns);
             }
           }
         } else
+#ifdef GMG_EXPERIMENTS
+        if (ctx->sgs_chain) hipLaunchKernelGGL(sgs_chain_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q, ctx->sgs_abort);
+        else
+#endif
         launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
       } else {
         launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
@@ -1915,10 +1926,19 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef GMG_EXPERIMENTS
+  HIPC(hipFuncSetAttribute((const void *)sgs_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
   // the sweep bakes absolute LDS addresses into its records: its dynamic LDS must start at 0 (no static __shared__)
   hipFuncAttributes fa{};
   HIPC(hipFuncGetAttributes(&fa, ph ? (const void *)sgs_phase_kernel : (const void *)sgs_wave_kernel<false>));
   G.wave = fa.sharedSizeBytes == 0;
+#ifdef GMG_EXPERIMENTS
+  if (ph) {
+    HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_chain_kernel));
+    G.wave = G.wave && fa.sharedSizeBytes == 0;
+  }
+#endif
   if (ctx->debug_upload && ph)
     std::fprintf(stderr, "[gmg] SGS step shapes: G %lld %lld %lld %lld | L1/4 %lld %lld %lld %lld %lld %lld %lld %lld | L2/8 %lld %lld %lld %lld\n", (long long)hist_g[0], (long long)hist_g[1],
                  (long long)hist_g[2], (long long)hist_g[3], (long long)hist_l1[0], (long long)hist_l1[1], (long long)hist_l1[2], (long long)hist_l1[3], (long long)hist_l1[4],
@@ -2710,6 +2730,12 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
+  else if (k == "sgs_chain") {
+#ifndef GMG_EXPERIMENTS
+    if (on) return fail(ctx, GMG_ERR_UNSUPPORTED, "sgs_chain needs a -DGMG_EXPERIMENTS build (tools/build_experiments.sh)");
+#endif
+    ctx->sgs_chain = on;
+  }
   else if (k == "sgs_phase_profile") {
     if (on && ctx->dist && ctx->comm.n_ranks > 1) return fail(ctx, GMG_ERR_INVALID, "sgs_phase_profile: one rank only (the instrumented sweep is a single-GPU measurement)");
     ctx->sgs_phase_profile = (int)value;

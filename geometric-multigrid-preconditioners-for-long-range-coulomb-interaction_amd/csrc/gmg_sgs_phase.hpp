@@ -41,7 +41,7 @@ constexpr int kPhMaxRows = 32;    // rows per step
 constexpr int kPhMaxEntries = 36; // 8 G + L of a range
 constexpr int kPhWaves = 4;       // compute waves
 constexpr int kPhThreads = 64 * (kPhWaves + 1);  // waves 0..3 compute, wave 4 prefetches the records into the L2
-constexpr int kPhJunk = 256;      // LDS bytes the prefetch wave's copies land in
+constexpr int kPhJunk = 512;      // LDS bytes behind the regions: [0, 256) the prefetch wave's copies land in, [256, 264) the hand-over words of gmg_sgs_chain.hpp
 constexpr int kPhYSlots = (160 * 1024 - kPhWaves * kPhRegion - kPhJunk) / 8 & ~1;  // doubles of y in LDS: 12256
 // a range's shape: 8 g head entries, l1 tail entries gathered in the dependent phase, l2 tail entries whose products are formed ahead
 __host__ __device__ constexpr bool ph_shape_ok(int g, int l1, int l2) {
