@@ -279,7 +279,7 @@ def main():
         rep = p.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed), marks + refines
         cycles.append({"cycle": cycle, "dofs": rep["dofs"], "dofs_by_level": rep["dofs_by_level"],
                        "outer_cg_iterations": rep["cg_iterations"], "coarse_cg_iterations": rep["coarse_iterations"],
-                       "solve_ms": round(rep["solve_seconds"] * 1e3, 3)})
+                       "solve_ms": round(rep["solve_seconds"] * 1e3, 3), "build_matrices_ms": round(rep["build_matrices_ms"], 3)})
     t_setup = time.time() - t_setup
     ctx = pkg.capi.Context.view(p.gmg_context())  # non-owning view of the problem's gmg_context (stats)
     comm_info = ctx.comm_info()
@@ -477,6 +477,11 @@ def main():
                        "dofs": dofs, "dofs_by_level": rep["dofs_by_level"], "outer_cg_iterations": its,
                        "coarse_cg_iterations_per_step": int(rep_t["coarse_iterations"]),
                        "level0_rows": int(n0), "level0_nnz": int(nnz0), "setup_seconds": round(t_setup, 2),
+                       # MGTransferPrebuilt::build_matrices (src/step-50.cc:957-958: inside the reference's Solve timer) of the timed
+                       # cycle, built on the device from the levels' vertex tables (gmg_build_transfer); not part of ms_per_step:
+                       # the operators of a cycle are built once, the step is the solve on them
+                       "build_matrices_ms": round(rep["build_matrices_ms"], 3),
+                       "level0_matrix": "formed on the device (gmg_set_level_matrix_lattice)" if (int(st.spmv0_layout) - 1) & 64 else "CSR from the host",
                        "transport": transport, "transport_note": transport_note, "communicator": comm_info,
                        "rccl_ranks": world if transport == "rccl" else 0, "peer_ranks": world if transport == "peer" else 0,
                        "gpus_visible": n_dev, "ranks_share_gpus": bool(shared),

@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/gmg_coulomb.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "gmg_create", "gmg_destroy", "gmg_reset", "gmg_last_error", "gmg_synchronize",
-    "gmg_set_system_matrix", "gmg_set_level_matrix", "gmg_set_edge_matrix", "gmg_set_prolongation",
+    "gmg_set_system_matrix", "gmg_set_level_matrix", "gmg_set_level_matrix_lattice", "gmg_set_edge_matrix", "gmg_set_prolongation", "gmg_build_transfer", "gmg_get_transfer",
     "gmg_set_copy_indices", "gmg_set_smoother", "gmg_set_coarse",
     "gmg_vec_alloc", "gmg_vec_free", "gmg_vec_upload", "gmg_vec_download", "gmg_vec_set_zero", "gmg_vec_equ",
     "gmg_vec_add", "gmg_vec_sadd", "gmg_vec_dot", "gmg_vec_norms", "gmg_vec_all_zero",
@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("spmv0_pattern_slices", C.c_int64), ("spmv0_slices", C.c_int64), ("coarse_enqueued", C.c_int64),
                 ("spmv0_noop_samples", C.c_int64), ("spmv0_noop_ms_total", C.c_double),
                 ("sgs_samples", C.c_int64), ("sgs_ms_total", C.c_double), ("sgs_substeps", C.c_int64), ("sgs_stream_bytes", C.c_int64),
-                ("sgs_launches", C.c_int64)]
+                ("sgs_launches", C.c_int64), ("build_matrices_ms", C.c_double)]
 
 
 class GMGError(RuntimeError):
@@ -150,6 +150,12 @@ class Context:
         self._chk(self.L.gmg_set_level_matrix(self.h, C.c_int(level), C.c_int64(m.n_rows), C.c_int64(m.n_cols),
                                               _p(rp, C.c_int64), _p(c, C.c_int32), _p(v, C.c_double)))
 
+    def set_level_matrix_lattice(self, level, nv, Ke):
+        """level 0 of an undivided lattice formed on the device: nv vertices per direction, Ke the 8 x 8 cell matrix"""
+        nv3 = (C.c_int32 * 3)(*[int(v) for v in nv])
+        ke = np.ascontiguousarray(Ke, dtype=np.float64).reshape(64)
+        self._chk(self.L.gmg_set_level_matrix_lattice(self.h, C.c_int(level), nv3, _p(ke, C.c_double)))
+
     def set_edge_matrix(self, level, m):
         rp, c, v = _csr(m)
         self._chk(self.L.gmg_set_edge_matrix(self.h, C.c_int(level), C.c_int64(m.n_rows), C.c_int64(m.n_cols),
@@ -159,6 +165,26 @@ class Context:
         rp, c, v = _csr(m)
         self._chk(self.L.gmg_set_prolongation(self.h, C.c_int(level), C.c_int64(m.n_rows), C.c_int64(m.n_cols),
                                               _p(rp, C.c_int64), _p(c, C.c_int32), _p(v, C.c_double)))
+
+    def build_transfer(self, level, dim, coarse_vertex, coarse_boundary, fine_vertex, fine_spacing):
+        """MGTransferPrebuilt::build_matrices on the device; returns the device time in ms"""
+        cv = np.ascontiguousarray(coarse_vertex, dtype=np.uint64)
+        cb = np.ascontiguousarray(coarse_boundary, dtype=np.uint8)
+        fv = np.ascontiguousarray(fine_vertex, dtype=np.uint64)
+        ms = C.c_double(0)
+        self._chk(self.L.gmg_build_transfer(self.h, C.c_int(level), C.c_int(dim), C.c_int64(len(cv)), _p(cv, C.c_uint64), _p(cb, C.c_uint8),
+                                            C.c_int64(len(fv)), _p(fv, C.c_uint64), C.c_uint64(int(fine_spacing)), C.byref(ms)))
+        return ms.value
+
+    def get_transfer(self, level, transposed=False):
+        from types import SimpleNamespace
+        nr, nc, nz = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.gmg_get_transfer(self.h, C.c_int(level), C.c_int(1 if transposed else 0), C.byref(nr), C.byref(nc), C.byref(nz), None, None, None))
+        rp = np.zeros(nr.value + 1, dtype=np.int64)
+        col, val = np.zeros(max(nz.value, 1), dtype=np.int32), np.zeros(max(nz.value, 1))
+        self._chk(self.L.gmg_get_transfer(self.h, C.c_int(level), C.c_int(1 if transposed else 0), C.byref(nr), C.byref(nc), C.byref(nz),
+                                          _p(rp, C.c_int64), _p(col, C.c_int32), _p(val, C.c_double)))
+        return SimpleNamespace(n_rows=nr.value, n_cols=nc.value, nnz=nz.value, rowptr=rp, col=col[:nz.value], val=val[:nz.value])
 
     def set_copy_indices(self, level, global_idx, level_idx):
         g = np.ascontiguousarray(global_idx, dtype=np.int32)

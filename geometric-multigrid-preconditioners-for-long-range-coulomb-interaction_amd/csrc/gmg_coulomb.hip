@@ -14,6 +14,7 @@
 #include "gmg_sgs_chain.hpp"  // hand-over through an LDS word instead of s_barrier: measured slower, kept as an experiment
 #endif
 #include "gmg_lattice.hpp"
+#include "gmg_transfer.hpp"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -69,6 +70,7 @@ struct DevCSR {
   uint8_t *lat_rowcls = nullptr;
   double *lat_ctab = nullptr;
   int32_t *lat_gen = nullptr;
+  bool lat_only = false;       // made by gmg_set_level_matrix_lattice: class table + row classes, no CSR / SELL copy
   int lat_W = 0;               // rows of the window that repeats with the plane stride (== lat_nxy: one contiguous interior)
   int64_t lat_fast_rows = 0;
   int lat_classes = 0, lat_nx = 0, lat_nxy = 0, lat_R0 = 0, lat_R1 = 0, lat_C = 0, lat_K = 0, lat_S = 0, lat_fast_blocks = 0, lat_n_gen = 0, lat_grid = 0;
@@ -175,6 +177,7 @@ struct gmg_context {
   std::vector<hipEvent_t> ev_a, ev_b;  // sampled level-0 SpMV launches
   std::vector<hipEvent_t> ev_c, ev_d;  // sampled update-kernel launches
   std::vector<hipEvent_t> ev_e, ev_f;  // SSOR sweep launches
+  bool launch_refused = false;  // launch_op met an operator / mode combination it has no kernel for (reported by launch_status)
   int ev_used = 0, ev2_used = 0, ev3_used = 0;
   long long sgs_launch_no = 0;
   hipEvent_t timed_start = nullptr, timed_stop = nullptr;  // next launch carries these as its dispatch start / stop events
@@ -215,7 +218,10 @@ namespace {
     return GMG_OK;                                                                \
   } while (0)
 
-int launch_status(gmg_context *ctx) { RETURN_LAUNCHED(ctx); }
+int launch_status(gmg_context *ctx) {
+  if (ctx->launch_refused) { ctx->launch_refused = false; return GMG_ERR_UNSUPPORTED; }
+  RETURN_LAUNCHED(ctx);
+}
 
 int fail(gmg_context *ctx, int code, const char *msg) {
   ctx->err = msg;
@@ -286,6 +292,21 @@ void parallel_chunks(int64_t n, F f) {
     if (b < e) th.emplace_back(f, b, e, t);
   }
   for (auto &x : th) x.join();
+}
+
+// Grid of spmv_lattice_kernel: m.lat_C columns x m.lat_K plane steps are cut into S segments per XCD slab -- 2.5 - 3 marching
+// waves per SIMD (measured at 121^3: 2 segments 13.0 us, 3 segments 11.8 us on a pure lattice) as long as a wave keeps >= 4
+// steps; the register budget admits four waves per SIMD = 1024 workgroups: what the marching waves leave free goes to the
+// rows outside the interior (per-entry gathers, ~10 x the cost of an interior row: about one chunk of 64 rows per wave).
+// Returns the number of workgroups for those rows.
+int lattice_grid(const gmg_context *ctx, DevCSR &m, size_t n_gen) {
+  const int slab = std::max(1, m.lat_K / 8);
+  int S = (int)std::max<int64_t>(1, (2816 / 8 + m.lat_C / 2) / m.lat_C);
+  S = std::min(S, std::max(1, slab / 4));
+  if (ctx->lattice_segments > 0) S = std::min(ctx->lattice_segments, slab);
+  m.lat_S = S;
+  m.lat_fast_blocks = 8 * ((S * m.lat_C + 3) / 4);
+  return n_gen == 0 ? 0 : (int)std::min<size_t>((size_t)std::max(64, 256 * kLatWavesPerSimd - m.lat_fast_blocks), (n_gen + 3) / 4);
 }
 
 // the lattice interior only needs the rows whose columns are owned (< n_rows): any n_cols >= n_rows qualifies
@@ -779,18 +800,7 @@ int upload_csr(gmg_context *ctx, DevCSR &m, int64_t n_rows, int64_t n_cols, cons
               m.lat_C = (int)((Wd + kLatRowsPerUnit - 1) / kLatRowsPerUnit);
               m.lat_K = (int)Kp;
               m.lat_fast_rows = n_fast;
-              // segments per XCD slab: 2.5 - 3 marching waves per SIMD (measured at 121^3: 2 segments 13.0 us, 3 segments 11.8 us
-              // on a pure lattice) as long as a wave keeps >= 4 steps; the register budget admits four waves per SIMD = 1024
-              // workgroups: what the marching waves leave free goes to the slices outside the interior
-              const int slab = std::max(1, m.lat_K / 8);
-              int S = (int)std::max<int64_t>(1, (2816 / 8 + m.lat_C / 2) / m.lat_C);
-              S = std::min(S, std::max(1, slab / 4));
-              if (ctx->lattice_segments > 0) S = std::min(ctx->lattice_segments, slab);
-              m.lat_S = S;
-              m.lat_fast_blocks = 8 * ((S * m.lat_C + 3) / 4);
-              // the slices outside the interior: per-entry gathers, ~10 x the cost of an interior row; one slice per wave if
-              // the launch stays resident at once
-              const int gen_blocks = gen.empty() ? 0 : (int)std::min<size_t>((size_t)std::max(64, 256 * kLatWavesPerSimd - m.lat_fast_blocks), (gen.size() + 3) / 4);
+              const int gen_blocks = lattice_grid(ctx, m, gen.size());
               m.lat_grid = m.lat_fast_blocks + gen_blocks;
               m.lat_n_gen = (int)gen.size();
               m.lat_gen_bytes = gen_bytes;
@@ -875,7 +885,7 @@ inline void launch_timed(gmg_context *ctx, K kernel, dim3 grid, dim3 block, size
 
 template <int MODE, int CG>
 int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
-  if (m.sell) {
+  if (m.sell || m.lat_only) {
     SellArgs sa{m.slice_ptr, m.slice_base, m.sell_vals, m.sell_cols, m.sell_dict, m.sell_spat, m.sell_pat, m.n_slices, (int)m.n_rows, a};
     if constexpr (MODE == kStore && (CG == 0 || CG == 2)) {
       if (m.lattice && !a.init) {
@@ -884,9 +894,15 @@ int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
         la.rowcls = m.lat_rowcls; la.ctab = m.lat_ctab; la.n_classes = m.lat_classes;
         la.nx = m.lat_nx; la.nxy = m.lat_nxy; la.W = m.lat_W; la.R0 = m.lat_R0; la.R1 = m.lat_R1; la.C = m.lat_C; la.K = m.lat_K; la.S = m.lat_S;
         la.fast_blocks = m.lat_fast_blocks; la.gen_slices = m.lat_gen; la.n_gen = m.lat_n_gen;
+        la.edge_mode = m.lat_only ? 1 : 0; la.n_rows = (int)m.n_rows;
         launch_timed(ctx, spmv_lattice_kernel<CG>, dim3(m.lat_grid), dim3(kThreads), 0, la);
         return m.lat_grid;
       }
+    }
+    if (m.lat_only) {  // (an operator that exists as a class table only: plain products and the coarse CG's three-kernel iteration)
+      ctx->err = "operator set by gmg_set_level_matrix_lattice: only y = A x and the three-kernel coarse CG are available";
+      ctx->launch_refused = true;
+      return 1;
     }
     if (m.use_sellp) {
       SellPatArgs pa{};
@@ -1252,7 +1268,7 @@ int coarse_solve(gmg_context *ctx, double *x, const double *b, int *iters_out, d
   const DevCSR &A = L0.A;
   if (!A.valid) return fail(ctx, GMG_ERR_INVALID, "level-0 matrix not set");
   int variant = ctx->cg_variant;
-  if (l0_partitioned(ctx) || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2)
+  if (l0_partitioned(ctx) || (variant == 0 && L0.n >= kUnfusedMinRowsDecl) || variant == 2 || A.lat_only)
   {
     ctx->stats.coarse_variant = 2;
     return coarse_solve_unfused(ctx, x, b, iters_out, res_out);
@@ -2029,6 +2045,23 @@ void release_operators(gmg_context *ctx) {
   free_cg_ring(ctx);
 }
 
+// tiles of the CSR row-window kernel: consecutive rows whose nonzeros fit the LDS window (as in upload_csr)
+template <class RP>
+std::vector<int32_t> window_tiles(const RP *rowptr, int64_t n_rows) {
+  std::vector<int32_t> tiles;
+  tiles.push_back(0);
+  int64_t r = 0;
+  while (r < n_rows) {
+    const int64_t ka = (int64_t)rowptr[r] & ~(int64_t)3;
+    int64_t e = r + 1;
+    while (e < n_rows && (int64_t)rowptr[e + 1] - ka <= kTileNnz && e - r < kTileMaxRowsEarly) ++e;
+    if ((int64_t)rowptr[e] - ka > kTileNnz) e = r + 1;
+    tiles.push_back((int32_t)e);
+    r = e;
+  }
+  return tiles;
+}
+
 DevCSR *which_matrix(gmg_context *ctx, int which) {
   if (which == GMG_SYSTEM) return &ctx->S;
   if (which < 0 || which >= ctx->n_levels) return nullptr;
@@ -2149,17 +2182,12 @@ int gmg_set_system_matrix(gmg_context *ctx, int64_t n_rows, int64_t n_cols, cons
   return GMG_OK;
 }
 
-int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
-                         const int32_t *col, const double *val) {
-  if (!ctx || level < 0 || level >= ctx->n_levels) return GMG_ERR_INVALID;
-  (void)hipSetDevice(ctx->device);
+// what a level needs besides its operator: work vectors and, on level 0, the coarse CG's vectors and the shape the bench reads
+static int finish_level(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, int64_t nnz) {
   Level &L = ctx->lv[(size_t)level];
-  CHK(upload_csr(ctx, L.A, n_rows, n_cols, rowptr, col, val, level > 0));
   L.n = n_rows;
   L.n_vec = n_cols;
-  CHK(setup_diag(ctx, n_rows, rowptr, col, val, &L.invd, &L.cheb_lmax));
   for (double **p : {&L.sol, &L.def, &L.t, &L.w1, &L.w2, &L.w3}) CHK(alloc_vec(ctx, p, n_cols));
-  if (level > 0) CHK(setup_sgs(ctx, L, n_rows, rowptr, col, val));
   if (level == 0) {
     if (l0_partitioned(ctx)) {
       const int64_t padded = part_chunk(ctx->l0_global, ctx->comm.n_ranks) * ctx->comm.n_ranks;
@@ -2176,7 +2204,7 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
     for (double **p : {&ctx->cg_g, &ctx->cg_d0, &ctx->cg_d1, &ctx->cg_h}) CHK(alloc_vec(ctx, p, n_cols));
     free_cg_ring(ctx);  // sized for the previous level 0
     ctx->stats.spmv0_rows = n_rows;
-    ctx->stats.spmv0_nnz = rowptr[n_rows];
+    ctx->stats.spmv0_nnz = nnz;
     ctx->stats.spmv0_layout = L.A.sell ? 1 + (L.A.val8 ? 2 : 0) + (L.A.col16 ? 4 : 0) + (L.A.use_sellp ? 8 : 0) : 0;
     if (L.A.sell) {
       const double frac_stream = L.A.n_slices ? 1.0 - (double)L.A.n_pattern_slices / L.A.n_slices : 1.0;
@@ -2189,8 +2217,11 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
         ctx->stats.spmv0_layout += 32;
         ctx->stats.spmv0_matrix_bytes = L.A.lat_fast_rows + L.A.lat_gen_bytes;
       }
+    } else if (L.A.lat_only) {  // class table only: one class byte per row
+      ctx->stats.spmv0_layout = 1 + 2 + 4 + 8 + 16 + 32 + 64;
+      ctx->stats.spmv0_matrix_bytes = n_rows;
     } else {
-      ctx->stats.spmv0_matrix_bytes = 12 * rowptr[n_rows] + 4 * (n_rows + 1);
+      ctx->stats.spmv0_matrix_bytes = 12 * nnz + 4 * (n_rows + 1);
     }
     ctx->stats.spmv0_pattern_slices = L.A.n_pattern_slices;
     ctx->stats.spmv0_slices = L.A.n_slices;
@@ -2198,6 +2229,126 @@ int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_
   }
   HIPC(hipStreamSynchronize(ctx->stream));
   return GMG_OK;
+}
+
+int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                         const int32_t *col, const double *val) {
+  if (!ctx || level < 0 || level >= ctx->n_levels) return GMG_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  Level &L = ctx->lv[(size_t)level];
+  CHK(upload_csr(ctx, L.A, n_rows, n_cols, rowptr, col, val, level > 0));
+  CHK(setup_diag(ctx, n_rows, rowptr, col, val, &L.invd, &L.cheb_lmax));
+  if (level > 0) {
+    L.n = n_rows;  // (the SGS plan reads it)
+    CHK(setup_sgs(ctx, L, n_rows, rowptr, col, val));
+  }
+  return finish_level(ctx, level, n_rows, n_cols, rowptr[n_rows]);
+}
+
+// The level matrix of an UNDIVIDED lattice level formed on the device: what gmg_set_level_matrix would
+// have received as CSR from assemble_multigrid (src/step-50.cc:869-889) for nv[0] x nv[1] x nv[2] vertices numbered
+// lexicographically, every cell adding the same 8 x 8 matrix Ke, all faces Dirichlet (MGConstrainedDoFs, :704-706):
+//   boundary vertex i:            a_ii = sum over its cells of |Ke[a][a]|, stored zeros elsewhere        (:877-879)
+//   interior vertex i, column j:  sum over the cells holding both of Ke[a_i][a_j], 0 if j is on the boundary
+// -- the sums in cell order (z, y, x ascending), from 0.0, exactly as CSRMatrix::add forms them: the same bits.  A vertex's
+// 27 coefficients depend only on its position type per direction (on the low face / next to it / inside / next to the
+// high face / on it): 125 classes.  The table is 125 x 27 numbers (host, microseconds); the per-row work -- class byte and
+// 1 / a_ii of 10^6..10^7 rows -- is a kernel.  No CSR, no upload.
+int gmg_set_level_matrix_lattice(gmg_context *ctx, int level, const int32_t nv[3], const double Ke[64]) {
+  if (!ctx || !nv || !Ke || level < 0 || level >= ctx->n_levels) return GMG_ERR_INVALID;
+  if (level != 0) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_set_level_matrix_lattice: level 0 only (finer levels of an adaptive hierarchy are patches, and their smoothers need the rows)");
+  if (l0_partitioned(ctx)) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_set_level_matrix_lattice: a row-partitioned level 0 takes its local rows as CSR (gmg_set_level_matrix)");
+  const int64_t nx = nv[0], ny = nv[1], nz = nv[2];
+  if (nx < 5 || ny < 5 || nz < 5) return fail(ctx, GMG_ERR_INVALID, "gmg_set_level_matrix_lattice: at least 5 vertices per direction");
+  const int64_t n = nx * ny * nz, nxy = nx * ny, reach = nxy + nx + 1;
+  if (n >= ((int64_t)1 << 28)) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_set_level_matrix_lattice: more than 2^28 rows");
+  (void)hipSetDevice(ctx->device);
+  Level &L = ctx->lv[0];
+  DevCSR &m = L.A;
+  HaloPlan keep = m.halo;
+  m.halo = HaloPlan();
+  free_csr(m);
+  m.halo = keep;
+  // ---- class table
+  const int64_t dims[3] = {nx, ny, nz};
+  auto rep = [&](int t, int64_t mdim) -> int64_t { return t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? mdim - 2 : mdim - 1; };
+  std::vector<double> ctab((size_t)125 * 27, 0.0);
+  double lmax = 0.0;
+  for (int cls = 0; cls < 125; ++cls) {
+    const int t[3] = {cls % 5, (cls / 5) % 5, cls / 25};
+    int64_t v[3];
+    bool v_bnd = false;
+    for (int d = 0; d < 3; ++d) { v[d] = rep(t[d], dims[d]); v_bnd = v_bnd || v[d] == 0 || v[d] == dims[d] - 1; }
+    double rowsum = 0.0;
+    for (int j = 0; j < 27; ++j) {
+      const int dd[3] = {j % 3 - 1, (j / 3) % 3 - 1, j / 9 - 1};
+      int64_t u[3];
+      bool exists = true, u_bnd = false;
+      for (int d = 0; d < 3; ++d) {
+        u[d] = v[d] + dd[d];
+        exists = exists && u[d] >= 0 && u[d] < dims[d];
+        u_bnd = u_bnd || u[d] == 0 || u[d] == dims[d] - 1;
+      }
+      double acc = 0.0;
+      if (exists && ((v_bnd && j == 13) || (!v_bnd && !u_bnd))) {
+        // the cells that hold both vertices, in cell order (z, y, x ascending)
+        int64_t lo[3], hi[3];
+        for (int d = 0; d < 3; ++d) { lo[d] = std::max<int64_t>(std::max(v[d], u[d]) - 1, 0); hi[d] = std::min<int64_t>(std::min(v[d], u[d]), dims[d] - 2); }
+        for (int64_t cz = lo[2]; cz <= hi[2]; ++cz)
+          for (int64_t cy = lo[1]; cy <= hi[1]; ++cy)
+            for (int64_t cx = lo[0]; cx <= hi[0]; ++cx) {
+              const int a = (int)((v[0] - cx) + 2 * (v[1] - cy) + 4 * (v[2] - cz)), b = (int)((u[0] - cx) + 2 * (u[1] - cy) + 4 * (u[2] - cz));
+              acc += v_bnd ? std::fabs(Ke[a * 8 + a]) : Ke[a * 8 + b];
+            }
+      }
+      ctab[(size_t)cls * 27 + (size_t)j] = acc;
+      rowsum += std::fabs(acc);
+    }
+    lmax = std::max(lmax, rowsum / std::fabs(ctab[(size_t)cls * 27 + 13]));  // Gershgorin bound of D^-1 A (every class occurs for n >= 5)
+  }
+  // position types with the same 27 coefficients share a class (most of the 125 do: the table every workgroup copies into
+  // its LDS shrinks to ~30 rows)
+  LatticeClassMap cmap{};
+  std::vector<double> utab;
+  int n_unique = 0;
+  for (int cls = 0; cls < 125; ++cls) {
+    int found = -1;
+    for (int q = 0; q < n_unique && found < 0; ++q)
+      if (std::memcmp(&utab[(size_t)q * 27], &ctab[(size_t)cls * 27], sizeof(double) * 27) == 0) found = q;
+    if (found < 0) {
+      found = n_unique++;
+      utab.insert(utab.end(), ctab.begin() + (std::ptrdiff_t)cls * 27, ctab.begin() + (std::ptrdiff_t)(cls + 1) * 27);
+    }
+    cmap.cls[cls] = (uint8_t)found;
+  }
+  HIPC(hipMalloc(&m.lat_rowcls, (size_t)n + 64));
+  HIPC(hipMalloc(&m.lat_ctab, sizeof(double) * utab.size()));
+  HIPC(hipMemcpyAsync(m.lat_ctab, utab.data(), sizeof(double) * utab.size(), hipMemcpyHostToDevice, ctx->stream));
+  CHK(alloc_vec(ctx, &L.invd, n));
+  hipLaunchKernelGGL(lattice_rowclass_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, m.lat_rowcls, L.invd, (const double *)m.lat_ctab, cmap, (int)nx, (int)ny, (int)nz);
+  CHK(launch_status(ctx));
+  HIPC(hipStreamSynchronize(ctx->stream));  // (utab dies with this scope)
+  L.cheb_lmax = lmax;
+  m.n_rows = m.n_cols = n;
+  m.nnz = (3 * nx - 2) * (3 * ny - 2) * (3 * nz - 2);
+  m.valid = true;
+  m.lattice = m.lat_only = true;
+  m.lat_classes = n_unique;
+  m.lat_nx = (int)nx; m.lat_nxy = (int)nxy; m.lat_W = (int)nxy;
+  m.lat_R0 = (int)(reach + 2); m.lat_R1 = (int)(n - reach);
+  if (m.lat_R1 - m.lat_R0 < nxy) return fail(ctx, GMG_ERR_INVALID, "gmg_set_level_matrix_lattice: fewer than five planes");
+  m.lat_C = (int)((nxy + kLatRowsPerUnit - 1) / kLatRowsPerUnit);
+  m.lat_K = (int)((m.lat_R1 - m.lat_R0 + nxy - 1) / nxy);
+  m.lat_fast_rows = m.lat_R1 - m.lat_R0;
+  m.lat_n_gen = (m.lat_R0 + 63) / 64 + (int)((n - m.lat_R1 + 63) / 64);
+  m.lat_gen_bytes = (int64_t)m.lat_n_gen * 64;
+  m.lat_grid = lattice_grid(ctx, m, (size_t)m.lat_n_gen);
+  m.lat_grid += m.lat_fast_blocks;
+  if (m.lat_grid > kMaxPartials) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_set_level_matrix_lattice: grid exceeds the reduction partials");
+  if (ctx->debug_upload)
+    std::fprintf(stderr, "[gmg] lattice operator %lld x %lld x %lld formed on the device: %d columns x %d steps, %d segments per XCD slab, grid %d, %d edge chunks\n", (long long)nx,
+                 (long long)ny, (long long)nz, m.lat_C, m.lat_K, m.lat_S, m.lat_grid, m.lat_n_gen);
+  return finish_level(ctx, 0, n, n, m.nnz);
 }
 
 int gmg_set_edge_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
@@ -2237,6 +2388,128 @@ int gmg_set_prolongation(gmg_context *ctx, int level, int64_t n_fine, int64_t n_
   transpose_host(n_fine, n_coarse, rowptr, col, val, trp, tcol, tval);
   CHK(upload_csr(ctx, L.Pt, n_coarse, n_fine, trp.data(), tcol.data(), tval.data()));
   L.has_P = true;
+  return GMG_OK;
+}
+
+// MGTransferPrebuilt::build_matrices on the device (gmg_transfer.hpp): P_level and its transpose from the vertices of the
+// DoFs of the two levels.  build_ms (may be null): device time of the build, the part the reference counts in its Solve timer.
+int gmg_build_transfer(gmg_context *ctx, int level, int dim, int64_t n_coarse, const uint64_t *coarse_vertex, const uint8_t *coarse_boundary,
+                       int64_t n_fine, const uint64_t *fine_vertex, uint64_t fine_spacing, double *build_ms) {
+  if (!ctx || level < 0 || level >= ctx->n_levels - 1 || (dim != 2 && dim != 3) || n_coarse <= 0 || n_fine <= 0 || !coarse_vertex || !coarse_boundary ||
+      !fine_vertex || fine_spacing == 0 || (fine_spacing & (fine_spacing - 1)) != 0)
+    return GMG_ERR_INVALID;
+  if (n_coarse >= ((int64_t)1 << 30) || n_fine >= ((int64_t)1 << 28)) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_build_transfer: level too large for 32-bit row pointers");
+  (void)hipSetDevice(ctx->device);
+  Level &L = ctx->lv[(size_t)level];
+  for (DevCSR *m : {&L.P, &L.Pt}) {
+    HaloPlan keep = m->halo;
+    m->halo = HaloPlan();
+    free_csr(*m);
+    m->halo = keep;
+  }
+  unsigned long long *d_fv = nullptr, *d_cv = nullptr, *d_fk = nullptr, *d_ck = nullptr;
+  uint8_t *d_cb = nullptr;
+  int32_t *d_fd = nullptr, *d_cd = nullptr;
+  auto cleanup = [&]() {
+    for (void *q : {(void *)d_fv, (void *)d_cv, (void *)d_fk, (void *)d_ck, (void *)d_cb, (void *)d_fd, (void *)d_cd})
+      if (q) (void)hipFree(q);
+  };
+  auto table_size = [](int64_t n) { unsigned long long t = 1024; while ((int64_t)t < 2 * n) t <<= 1; return t; };
+  const unsigned long long ft = table_size(n_fine), ct = table_size(n_coarse);
+#define TRC(call) do { if ((call) != hipSuccess) { cleanup(); return fail(ctx, GMG_ERR_HIP, "gmg_build_transfer: " #call " failed"); } } while (0)
+  TRC(hipMalloc(&d_fv, sizeof(uint64_t) * (size_t)n_fine));
+  TRC(hipMalloc(&d_cv, sizeof(uint64_t) * (size_t)n_coarse));
+  TRC(hipMalloc(&d_cb, (size_t)n_coarse));
+  TRC(hipMalloc(&d_fk, sizeof(uint64_t) * ft));
+  TRC(hipMalloc(&d_ck, sizeof(uint64_t) * ct));
+  TRC(hipMalloc(&d_fd, sizeof(int32_t) * ft));
+  TRC(hipMalloc(&d_cd, sizeof(int32_t) * ct));
+  TRC(hipMemcpyAsync(d_fv, fine_vertex, sizeof(uint64_t) * (size_t)n_fine, hipMemcpyHostToDevice, ctx->stream));
+  TRC(hipMemcpyAsync(d_cv, coarse_vertex, sizeof(uint64_t) * (size_t)n_coarse, hipMemcpyHostToDevice, ctx->stream));
+  TRC(hipMemcpyAsync(d_cb, coarse_boundary, (size_t)n_coarse, hipMemcpyHostToDevice, ctx->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  TRC(hipEventCreate(&e0));
+  TRC(hipEventCreate(&e1));
+  TRC(hipEventRecord(e0, ctx->stream));
+  TRC(hipMemsetAsync(d_fk, 0xff, sizeof(uint64_t) * ft, ctx->stream));
+  TRC(hipMemsetAsync(d_ck, 0xff, sizeof(uint64_t) * ct, ctx->stream));
+  hipLaunchKernelGGL(tr_table_build_kernel, dim3(grid_for(n_fine)), dim3(kThreads), 0, ctx->stream, (const unsigned long long *)d_fv, n_fine, d_fk, d_fd, ft - 1);
+  hipLaunchKernelGGL(tr_table_build_kernel, dim3(grid_for(n_coarse)), dim3(kThreads), 0, ctx->stream, (const unsigned long long *)d_cv, n_coarse, d_ck, d_cd, ct - 1);
+  TransferArgs a{};
+  a.fine_vertex = d_fv; a.coarse_vertex = d_cv; a.coarse_boundary = d_cb; a.n_fine = n_fine; a.n_coarse = n_coarse;
+  a.fkeys = d_fk; a.ckeys = d_ck; a.fdof = d_fd; a.cdof = d_cd; a.fmask = ft - 1; a.cmask = ct - 1; a.dim = dim; a.half = fine_spacing;
+  // one operator after the other: count, scan, allocate, fill
+  auto build = [&](DevCSR &m, bool transposed) -> int {
+    const int64_t nr = transposed ? n_coarse : n_fine, nc = transposed ? n_fine : n_coarse;
+    HIPC(hipMalloc(&m.rowptr, sizeof(int32_t) * ((size_t)nr + 1)));
+    a.rowptr = m.rowptr;
+    if (transposed) hipLaunchKernelGGL(tr_restriction_kernel<false>, dim3(grid_for(nr)), dim3(kThreads), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(tr_prolongation_kernel<false>, dim3(grid_for(nr)), dim3(kThreads), 0, ctx->stream, a);
+    hipLaunchKernelGGL(tr_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.rowptr, nr);
+    int32_t nnz = 0;
+    HIPC(hipMemcpyAsync(&nnz, m.rowptr + nr, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    const size_t pad = 8;
+    HIPC(hipMalloc(&m.col, sizeof(int32_t) * ((size_t)nnz + pad)));
+    HIPC(hipMalloc(&m.val, sizeof(double) * ((size_t)nnz + pad)));
+    HIPC(hipMemsetAsync(m.col + nnz, 0, sizeof(int32_t) * pad, ctx->stream));
+    HIPC(hipMemsetAsync(m.val + nnz, 0, sizeof(double) * pad, ctx->stream));
+    a.col = m.col; a.val = m.val;
+    if (transposed) hipLaunchKernelGGL(tr_restriction_kernel<true>, dim3(grid_for(nr)), dim3(kThreads), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(tr_prolongation_kernel<true>, dim3(grid_for(nr)), dim3(kThreads), 0, ctx->stream, a);
+    m.n_rows = nr; m.n_cols = nc; m.nnz = nnz;
+    return launch_status(ctx);
+  };
+  int rc = build(L.P, false);
+  if (rc == GMG_OK) rc = build(L.Pt, true);
+  if (rc == GMG_OK && hipEventRecord(e1, ctx->stream) != hipSuccess) rc = GMG_ERR_HIP;
+  // the row-window tiling of the two operators (host: a pass over the row pointers)
+  for (DevCSR *m : {&L.P, &L.Pt}) {
+    if (rc != GMG_OK) break;
+    std::vector<int32_t> rp((size_t)m->n_rows + 1);
+    if (hipMemcpyAsync(rp.data(), m->rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = GMG_ERR_HIP; break; }
+    const std::vector<int32_t> tiles = window_tiles(rp.data(), m->n_rows);
+    m->n_tiles = (int)tiles.size() - 1;
+    m->tiles_per_xcd = (m->n_tiles + 7) / 8;
+    m->grid = 8 * std::min(kMaxPartials / 8, std::max(1, m->tiles_per_xcd));
+    if (hipMalloc(&m->tile_row, sizeof(int32_t) * tiles.size()) != hipSuccess ||
+        hipMemcpyAsync(m->tile_row, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = GMG_ERR_HIP; break; }
+    m->valid = true;
+  }
+  float ms = 0.f;
+  if (rc == GMG_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 0.f;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+#undef TRC
+  cleanup();
+  if (rc != GMG_OK) { if (ctx->err.empty()) ctx->err = "gmg_build_transfer failed"; return rc; }
+  L.has_P = true;
+  ctx->stats.build_matrices_ms += ms;
+  if (build_ms) *build_ms = ms;
+  if (ctx->debug_upload)
+    std::fprintf(stderr, "[gmg] transfer %d -> %d built on the device: P %lld x %lld nnz %lld, P^T nnz %lld, %.3f ms\n", level, level + 1, (long long)n_fine, (long long)n_coarse,
+                 (long long)L.P.nnz, (long long)L.Pt.nnz, ms);
+  return GMG_OK;
+}
+
+// CSR of P_level (transposed = 0) or its transpose as the device holds it (tests): sizes first (arrays null), then the copy
+int gmg_get_transfer(gmg_context *ctx, int level, int transposed, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *rowptr, int32_t *col, double *val) {
+  if (!ctx || level < 0 || level >= ctx->n_levels - 1) return GMG_ERR_INVALID;
+  const DevCSR &m = transposed ? ctx->lv[(size_t)level].Pt : ctx->lv[(size_t)level].P;
+  if (!m.valid || !m.rowptr || !m.col || !m.val) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_get_transfer: no CSR copy of this operator on the device");
+  if (n_rows) *n_rows = m.n_rows;
+  if (n_cols) *n_cols = m.n_cols;
+  if (nnz) *nnz = m.nnz;
+  if (!rowptr) return GMG_OK;
+  std::vector<int32_t> rp((size_t)m.n_rows + 1);
+  HIPC(hipMemcpyAsync(rp.data(), m.rowptr, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, ctx->stream));
+  if (m.nnz) {
+    HIPC(hipMemcpyAsync(col, m.col, sizeof(int32_t) * (size_t)m.nnz, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(val, m.val, sizeof(double) * (size_t)m.nnz, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < rp.size(); ++i) rowptr[i] = rp[i];
   return GMG_OK;
 }
 

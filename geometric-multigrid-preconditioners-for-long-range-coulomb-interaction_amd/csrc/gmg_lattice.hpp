@@ -30,7 +30,7 @@
 
 namespace gmg {
 
-constexpr int kLatMaxClasses = 96;  // 27 doubles each in LDS: 20.7 KB
+constexpr int kLatMaxClasses = 128;  // 27 doubles each in LDS: 27.6 KB (125 = the position types of gmg_set_level_matrix_lattice)
 constexpr int kLatRowsPerUnit = 124;
 constexpr int kLatAhead = 1;         // plane steps of loads in flight beyond the one being summed
 constexpr int kLatWavesPerSimd = 4;  // register budget of the kernel (128 VGPRs): the window of planes lives in registers
@@ -50,6 +50,10 @@ struct LatArgs {
   int fast_blocks;        // workgroups [0, fast_blocks) march; the others serve gen_slices
   const int32_t *gen_slices;
   int n_gen;
+  // edge_mode = 1 (operators made by gmg_set_level_matrix_lattice: no SELL streams exist): the rows outside [R0, R1) are
+  // served from the class table too, row by row with guarded gathers; n_gen then counts chunks of 64 such rows
+  int edge_mode;
+  int n_rows;
 };
 
 namespace lat {
@@ -113,6 +117,42 @@ __device__ __forceinline__ void lattice_generic_slice(const SellPatArgs &pa, int
   if (valid) {
     a.y[row] = acc;
     if constexpr (CG == 2) dot_acc += a.x[row] * acc;
+  }
+}
+
+// A chunk of 64 rows outside the lattice interior of a pure lattice operator (edge_mode): the first R0 and the last
+// n - R1 rows of the numbering.  Lane = row; the 27 coefficients of the row's class against x at the 27 lattice offsets, in
+// entry order; an offset that leaves [0, n) reads nothing (its coefficient is +0.0: the neighbour does not exist).
+template <int CG>
+__device__ __forceinline__ void lattice_edge_chunk(const LatArgs &A, int chunk, int lane, const double *ctab, double &dot_acc) {
+  const SpmvArgs &a = A.pa.sa.a;
+  const int head = (A.R0 + 63) >> 6;  // chunks of the head rows [0, R0)
+  const int row = chunk < head ? chunk * 64 + lane : A.R1 + (chunk - head) * 64 + lane;
+  const bool valid = chunk < head ? row < A.R0 : row < A.n_rows;
+  if (!valid) return;
+  const double *cw = ctab + (int)A.rowcls[row] * 27;
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 27; ++j) {
+    const int col = row + (j / 9 - 1) * A.nxy + ((j / 3) % 3 - 1) * A.nx + (j % 3 - 1);
+    const double xv = (col >= 0 && col < A.n_rows) ? a.x[col] : 0.0;
+    acc += cw[j] * xv;
+  }
+  a.y[row] = acc;
+  if constexpr (CG == 2) dot_acc += a.x[row] * acc;
+}
+
+// gmg_set_level_matrix_lattice: class byte of every vertex of an nx x ny x nz lattice (position type per direction: on the
+// low face, next to it, inside, next to the high face, on it -> 5 x 5 x 5 classes) and 1 / a_ii from the class table.
+struct LatticeClassMap { uint8_t cls[125]; };  // position type (tx + 5 ty + 25 tz) -> class (types with equal coefficients share one)
+__global__ __launch_bounds__(kThreads) void lattice_rowclass_kernel(uint8_t *rowcls, double *invd, const double *ctab, LatticeClassMap cmap, int nx, int ny, int nz) {
+  const long long n = (long long)nx * ny * nz;
+  for (long long r = (long long)blockIdx.x * kThreads + threadIdx.x; r < n; r += (long long)gridDim.x * kThreads) {
+    const int x = (int)(r % nx), y = (int)((r / nx) % ny), z = (int)(r / ((long long)nx * ny));
+    auto type = [](int c, int m) { return c == 0 ? 0 : c == m - 1 ? 4 : c == 1 ? 1 : c == m - 2 ? 3 : 2; };
+    const int cls = cmap.cls[type(x, nx) + 5 * type(y, ny) + 25 * type(z, nz)];
+    rowcls[r] = (uint8_t)cls;
+    invd[r] = 1.0 / ctab[cls * 27 + 13];
   }
 }
 
@@ -284,10 +324,16 @@ __global__ __launch_bounds__(kThreads, kLatWavesPerSimd) void spmv_lattice_kerne
     if constexpr (CG == 2) {
       if (a.st->done) return;
     }
-    dict[threadIdx.x] = A.pa.sa.dict[threadIdx.x];
-    __syncthreads();
     const int gw = ((int)blockIdx.x - A.fast_blocks) * 4 + wid, n_gw = ((int)gridDim.x - A.fast_blocks) * 4;
-    for (int i = gw; i < A.n_gen; i += n_gw) lattice_generic_slice<CG>(A.pa, A.R0, A.R1, A.nxy, A.W, __builtin_amdgcn_readfirstlane(A.gen_slices[i]), lane, dict, dot_acc);
+    if (A.edge_mode) {
+      for (int i = threadIdx.x; i < A.n_classes * 27; i += kThreads) ctab[i] = A.ctab[i];
+      __syncthreads();
+      for (int i = gw; i < A.n_gen; i += n_gw) lattice_edge_chunk<CG>(A, i, lane, ctab, dot_acc);
+    } else {
+      dict[threadIdx.x] = A.pa.sa.dict[threadIdx.x];
+      __syncthreads();
+    }
+    for (int i = gw; i < (A.edge_mode ? 0 : A.n_gen); i += n_gw) lattice_generic_slice<CG>(A.pa, A.R0, A.R1, A.nxy, A.W, __builtin_amdgcn_readfirstlane(A.gen_slices[i]), lane, dict, dot_acc);
   }
   if constexpr (CG != 0) {
     const double sblock = block_sum(dot_acc, red);

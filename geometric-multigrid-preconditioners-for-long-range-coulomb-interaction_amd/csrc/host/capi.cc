@@ -36,6 +36,8 @@ int guarded(step50_problem *h, F f) {
 const CSRMatrix *pick_matrix(step50_problem *h, int kind, int level) {
   // kind 0 system, 1 level, 2 edge, 3 prolongation
   if (kind == 0) return &DISPATCH(h, system_matrix);
+  if (kind == 1) DISPATCH(h, ensure_level_matrix(level));  // (level 0 may have been left to the device: assemble it now)
+  if (kind == 3) DISPATCH(h, ensure_prolongation(level));   // (the transfers likewise)
   auto &v = kind == 1 ? DISPATCH(h, mg_matrices) : kind == 2 ? DISPATCH(h, mg_interface_matrices) : DISPATCH(h, mg_prolongation);
   if (level < 0 || level >= (int)v.size()) return nullptr;
   return &v[(size_t)level];
@@ -151,6 +153,7 @@ struct step50_report {
   double starting_value, convergence_value, sol_l1, sol_l2, sol_linf, refine_threshold;
   double energy_analytical, energy_short, energy_fe_long, energy_self, energy_total, energy_abs_error;
   double solve_seconds, energy_norm_error;
+  double build_matrices_ms;  // device time of MGTransferPrebuilt::build_matrices (gmg_build_transfer) for this cycle; 0: built on the host
 };
 int step50_get_report(step50_problem *h, int i, step50_report *out) {
   const auto &reps = DISPATCH(h, reports);
@@ -170,6 +173,7 @@ int step50_get_report(step50_problem *h, int i, step50_report *out) {
   out->energy_self = r.energy_self; out->energy_total = r.energy_total; out->energy_abs_error = r.energy_abs_error;
   out->solve_seconds = r.solve_seconds;
   out->energy_norm_error = r.energy_norm_error;
+  out->build_matrices_ms = r.build_matrices_ms;
   return 0;
 }
 

@@ -209,7 +209,12 @@ void ParameterReader::declare_parameters() {
             {"Refinement estimator", "Kelly + residual"},
             // level 0 is the undivided lattice: numbered lexicographically (x fastest) its operator is a pure 27-point
             // stencil for the device's plane-by-plane kernel; "cell-wise" = deal.II's first-touch order on level 0 as well
-            {"Level 0 numbering", "lexicographic"}};
+            {"Level 0 numbering", "lexicographic"},
+            // the level-0 matrix formed on the device from (lattice size, cell matrix) instead of assembled here and uploaded
+            // as CSR (gmg_set_level_matrix_lattice; 3D constant-coefficient problems with a lexicographic, unpartitioned level 0)
+            {"Level 0 matrix on device", "true"},
+            // MGTransferPrebuilt::build_matrices on the device (gmg_build_transfer) instead of here + upload
+            {"Transfer matrices on device", "true"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -275,6 +280,8 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
   p.refinement_estimator = prm.get("Refinement estimator");
   if (p.refinement_estimator != "Kelly + residual" && p.refinement_estimator != "Kelly")
     throw std::runtime_error("Refinement estimator must be <Kelly + residual> or <Kelly>");
+  p.level0_matrix_on_device = prm.get_bool("Level 0 matrix on device");
+  p.transfer_on_device = prm.get_bool("Transfer matrices on device");
   p.level0_numbering = prm.get("Level 0 numbering");
   if (p.level0_numbering != "lexicographic" && p.level0_numbering != "cell-wise")
     throw std::runtime_error("Level 0 numbering must be <lexicographic> or <cell-wise>");
@@ -885,12 +892,57 @@ void LaplaceProblem<dim>::assemble_multigrid() {
   const bool constant_coef = par.Problemtype != "Step16";
   mg_matrices.assign((size_t)L, {});
   mg_interface_matrices.assign((size_t)L, {});
+  level0_on_device = decide_level0_on_device();
+  for (int l = 0; l < L; ++l) {
+    if (l == 0 && level0_on_device) continue;  // formed on the device at upload; assembled here only when somebody asks for it
+    assemble_level(l);
+  }
+}
+
+// Is level 0 the kind of operator gmg_set_level_matrix_lattice forms (and is it going to stay whole on this rank)?
+template <int dim>
+bool LaplaceProblem<dim>::decide_level0_on_device() const {
+  if (!par.level0_matrix_on_device || !solve_on_device_requested || dim != 3 || par.Problemtype == "Step16" || par.level0_numbering != "lexicographic") return false;
+  if (triangulation.n0 + 1 < 5) return false;
+  if (distributed) {  // the same decision upload() takes about partitioning level 0
+    const int64_t n0 = (int64_t)level_vertex_of_dof[0].size();
+    const bool peer_transport = comm_id.compare(0, 8, "GMGPEER:") == 0;
+    const bool part = par.partition_level0 == "always" ||
+                      (par.partition_level0 != "never" && n0 - n0 / n_ranks >= (peer_transport ? kPartitionMinRowsSavedPeer : kPartitionMinRowsSaved));
+    if (part) return false;
+  }
+  return true;
+}
+
+// the 8 x 8 cell matrix every level-0 cell adds (constant coefficient), as assemble_level forms it
+template <int dim>
+void LaplaceProblem<dim>::level0_cell_matrix(double *Ke) const {
+  constexpr int nv = 1 << dim;
+  const Quadrature<dim> q_laplace((int)par.degree + 1);
+  double Kc[nv][nv];
+  double x0[3] = {0, 0, 0};
+  cell_matrix<dim>(q_laplace, 1.0, x0, [&](const double *) { return 1.0; }, true, Kc);
+  const double s = std::pow(triangulation.cell_size(0), dim - 2);
+  for (int i = 0; i < nv; ++i)
+    for (int j = 0; j < nv; ++j) Ke[i * nv + j] = Kc[i][j] * s;
+}
+
+template <int dim>
+void LaplaceProblem<dim>::ensure_level_matrix(int l) {
+  if (l >= 0 && l < (int)mg_matrices.size() && mg_matrices[(size_t)l].n_rows == 0 && !level_vertex_of_dof[(size_t)l].empty()) assemble_level(l);
+}
+
+template <int dim>
+void LaplaceProblem<dim>::assemble_level(int l) {
+  constexpr int nv = 1 << dim;
+  const Quadrature<dim> q_laplace((int)par.degree + 1);
+  const bool constant_coef = par.Problemtype != "Step16";
   double Kc[nv][nv];
   if (constant_coef) {
     double x0[3] = {0, 0, 0};
     cell_matrix<dim>(q_laplace, 1.0, x0, [&](const double *) { return 1.0; }, true, Kc);
   }
-  for (int l = 0; l < L; ++l) {
+  {
     const auto &cells = triangulation.levels[(size_t)l];
     const int64_t n = (int64_t)level_vertex_of_dof[(size_t)l].size();
     std::vector<int64_t> cptr(cells.size() + 1, 0);
@@ -941,13 +993,12 @@ void LaplaceProblem<dim>::assemble_multigrid() {
 }
 
 template <int dim>
-void LaplaceProblem<dim>::build_transfer() {
-  // MGTransferPrebuilt::build_matrices (:957-958): Q1 embedding per child, columns of coarse
-  // boundary DoFs zeroed; copy_indices for PreconditionMG (active cells, not on the refinement edge)
+void LaplaceProblem<dim>::build_prolongation(int l) {
+  // MGTransferPrebuilt::build_matrices (:957-958) for one level pair: Q1 embedding per child, columns of coarse boundary DoFs
+  // zeroed.  With "Transfer matrices on device" the device forms the same operator from the two levels' vertex tables
+  // (gmg_build_transfer) and this host version only runs when somebody asks for the matrix (tests, the CPU oracle).
   constexpr int nv = 1 << dim;
-  const int L = triangulation.n_levels();
-  mg_prolongation.assign((size_t)std::max(0, L - 1), {});
-  for (int l = 0; l + 1 < L; ++l) {
+  {
     std::vector<std::array<int64_t, 2>> rc;
     std::vector<double> v;
     const auto &cells = triangulation.levels[(size_t)l];
@@ -974,6 +1025,21 @@ void LaplaceProblem<dim>::build_transfer() {
     mg_prolongation[(size_t)l] =
         csr_from_triplets((int64_t)level_vertex_of_dof[(size_t)l + 1].size(), (int64_t)level_vertex_of_dof[(size_t)l].size(), rc, v, false);
   }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::ensure_prolongation(int l) {
+  if (l >= 0 && l < (int)mg_prolongation.size() && mg_prolongation[(size_t)l].n_rows == 0) build_prolongation(l);
+}
+
+template <int dim>
+void LaplaceProblem<dim>::build_transfer() {
+  // mg_transfer.build_matrices (:957-958) + the copy_indices of PreconditionMG (active cells, not on the refinement edge)
+  constexpr int nv = 1 << dim;
+  const int L = triangulation.n_levels();
+  mg_prolongation.assign((size_t)std::max(0, L - 1), {});
+  transfer_on_device = par.transfer_on_device && solve_on_device_requested;
+  for (int l = 0; l + 1 < L && !transfer_on_device; ++l) build_prolongation(l);
   copy_global.assign((size_t)L, {});
   copy_level.assign((size_t)L, {});
   for (int l = 0; l < L; ++l) {
@@ -1029,6 +1095,7 @@ int LaplaceProblem<dim>::upload() {
     GMGC(gmg_reset(gmg, L));  // the context may have been created early (charge densities) with 1 level
   }
   operators_uploaded = true;
+  build_matrices_ms = 0.0;
   // before the level matrices: sizes the SGS schedule.  0 = one block per rank: the reference's smoother on that many ranks
   GMGC(gmg_set_ssor_blocks(gmg, par.ssor_blocks > 0 ? par.ssor_blocks : std::max(1, distributed ? n_ranks : 1)));
   const CSRMatrix &S = system_matrix;
@@ -1036,7 +1103,7 @@ int LaplaceProblem<dim>::upload() {
     // system matrix + outer-CG vectors and level 0 are row-partitioned (canonical equal chunks),
     // levels >= 1, transfers and copy indices are replicated.  A level 0 whose
     // coarse-CG iteration is shorter than the three collectives it would need stays replicated.
-    const int64_t n0 = mg_matrices[0].n_rows;
+    const int64_t n0 = (int64_t)level_vertex_of_dof[0].size();
     // rows taken off every rank's coarse iteration against what the exchange costs on the transport in use
     const bool peer_transport = comm_id.compare(0, 8, "GMGPEER:") == 0;
     level0_partitioned = par.partition_level0 == "always" ||
@@ -1052,8 +1119,18 @@ int LaplaceProblem<dim>::upload() {
     d_begin = 0; d_n = d_nvec = S.n_rows;
   }
   for (int l = 0; l < L; ++l) {
+    if (l == 0 && level0_on_device && !(distributed && level0_partitioned)) {
+      // the lattice operator is formed on the device from its size and the cell matrix
+      double Ke[64];
+      level0_cell_matrix(Ke);
+      const int32_t nvv[3] = {triangulation.n0 + 1, triangulation.n0 + 1, triangulation.n0 + 1};
+      GMGC(gmg_set_level_matrix_lattice(gmg, 0, nvv, Ke));
+    } else {
+      ensure_level_matrix(l);
+    }
     const CSRMatrix &A = mg_matrices[(size_t)l];
-    if (distributed && level0_partitioned && l == 0) {
+    if (l == 0 && level0_on_device && !(distributed && level0_partitioned)) {
+    } else if (distributed && level0_partitioned && l == 0) {
       const LocalOperator Al = localize(A, rank, n_ranks);
       GMGC(gmg_set_level_matrix(gmg, 0, Al.A.n_rows, Al.A.n_cols, Al.A.rowptr.data(), Al.A.col.data(), Al.A.val.data()));
       GMGC(gmg_set_halo_plan(gmg, 0, (int)Al.halo.neighbor_rank.size(), Al.halo.neighbor_rank.data(), Al.halo.send_count.data(),
@@ -1064,7 +1141,15 @@ int LaplaceProblem<dim>::upload() {
     const CSRMatrix &I = mg_interface_matrices[(size_t)l];
     if (I.nnz() > 0) GMGC(gmg_set_edge_matrix(gmg, l, I.n_rows, I.n_cols, I.rowptr.data(), I.col.data(), I.val.data()));
     GMGC(gmg_set_copy_indices(gmg, l, (int64_t)copy_global[(size_t)l].size(), copy_global[(size_t)l].data(), copy_level[(size_t)l].data()));
-    if (l + 1 < L) {
+    if (l + 1 < L && transfer_on_device) {
+      // P_l and its transpose are formed on the device from the vertex tables of the two levels
+      std::vector<uint8_t> bnd(level_boundary[(size_t)l].begin(), level_boundary[(size_t)l].end());
+      double ms = 0.0;
+      GMGC(gmg_build_transfer(gmg, l, dim, (int64_t)level_vertex_of_dof[(size_t)l].size(), level_vertex_of_dof[(size_t)l].data(), bnd.data(),
+                              (int64_t)level_vertex_of_dof[(size_t)l + 1].size(), level_vertex_of_dof[(size_t)l + 1].data(),
+                              (uint64_t)1 << (kMaxLevelShift - (l + 1)), &ms));
+      build_matrices_ms += ms;
+    } else if (l + 1 < L) {
       const CSRMatrix &P = mg_prolongation[(size_t)l];
       GMGC(gmg_set_prolongation(gmg, l, P.n_rows, P.n_cols, P.rowptr.data(), P.col.data(), P.val.data()));
     }
@@ -1151,6 +1236,7 @@ int LaplaceProblem<dim>::solve_on_device(CycleReport &rep) {
   }
   gmg_synchronize(gmg);
   rep.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  rep.build_matrices_ms = build_matrices_ms;
   rep.starting_value = control.initial_value;
   rep.cg_iterations = control.last_step;
   rep.convergence_value = control.last_value;
@@ -1354,6 +1440,7 @@ int LaplaceProblem<dim>::run_cycle(unsigned int cycle, bool on_device) {
     t_last = now;
   };
   densities_on_device = on_device && par.densities_on_device;
+  solve_on_device_requested = on_device;
   if (cycle == 0) make_initial_grid();
   else refine_grid(cycle);
   lap("mesh");

@@ -65,6 +65,8 @@ struct Parameters {
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
   std::string refinement_estimator = "Kelly + residual";  // HEAD (:1040-1089) | "Kelly": the indicator of the older cluster runs
+  bool transfer_on_device = true;       // gmg_build_transfer instead of building P_l here and uploading it
+  bool level0_matrix_on_device = true;  // gmg_set_level_matrix_lattice instead of assembling + uploading level 0 (3D, constant coefficient, lexicographic, unpartitioned)
   std::string level0_numbering = "lexicographic";  // lexicographic | cell-wise (deal.II's first-touch order): level 0 carries no smoother
   static Parameters from(const ParameterReader &prm);
 };
@@ -82,6 +84,7 @@ struct CycleReport {  // the values the reference prints per cycle (src/step-50.
   double energy_analytical = 0, energy_short = 0, energy_fe_long = 0, energy_self = 0, energy_total = 0, energy_abs_error = 0;
   double energy_norm_error = 0;
   double solve_seconds = 0;  // first residual to convergence, excluding upload / build_matrices
+  double build_matrices_ms = 0;  // device time of mg_transfer.build_matrices (:957-958) when the device builds the transfers
   int status = 0;
 };
 
@@ -102,7 +105,13 @@ class LaplaceProblem {
   void compute_moments();                                                // :577-644
   void assemble_system();                                                // :735-833
   void assemble_multigrid();                                             // :835-933
+  void assemble_level(int l);                                            // one level's matrix + interface matrix (:869-931)
+  void ensure_level_matrix(int l);                                       // assemble a level that was left to the device, on demand
+  bool decide_level0_on_device() const;                                  // level 0 formed on the device (gmg_set_level_matrix_lattice)?
+  void level0_cell_matrix(double *Ke) const;
   void build_transfer();                                                 // mg_transfer.build_matrices, :957-958
+  void build_prolongation(int l);                                        // P_l on the host (the device builds it otherwise)
+  void ensure_prolongation(int l);
   int ensure_context();                                                  // gmg_create (+ communicator) on first use
   int upload();                                                          // hand the operators over the C-ABI
   int solve();                                                           // :938-1017
@@ -133,6 +142,8 @@ class LaplaceProblem {
   bool echo = false;
   gmg_context *gmg = nullptr;
   bool operators_uploaded = false, densities_on_device = false;
+  bool solve_on_device_requested = false, level0_on_device = false, transfer_on_device = false;
+  double build_matrices_ms = 0.0;  // device time of gmg_build_transfer for the current cycle's operators
   std::string last_error;
   // one process per GPU (the reference: one MPI rank per subdomain, src/main.cc:8); the host
   // setup is replicated, the operators are cut by partition.h at upload()

@@ -25,7 +25,7 @@ class Report(C.Structure):
                 ("sol_l1", C.c_double), ("sol_l2", C.c_double), ("sol_linf", C.c_double), ("refine_threshold", C.c_double),
                 ("energy_analytical", C.c_double), ("energy_short", C.c_double), ("energy_fe_long", C.c_double),
                 ("energy_self", C.c_double), ("energy_total", C.c_double), ("energy_abs_error", C.c_double),
-                ("solve_seconds", C.c_double), ("energy_norm_error", C.c_double)]
+                ("solve_seconds", C.c_double), ("energy_norm_error", C.c_double), ("build_matrices_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("dofs_by_level", "pad")}
@@ -78,6 +78,8 @@ def prm_text(**kw) -> str:
         "partition_level0": ("Solver input data", "Partition level 0"),
         "refinement_estimator": ("Misc", "Refinement estimator"),
         "level0_numbering": ("Misc", "Level 0 numbering"),
+        "level0_on_device": ("Misc", "Level 0 matrix on device"),
+        "transfer_on_device": ("Misc", "Transfer matrices on device"),
     }
     sections = {}
     for k, v in kw.items():

@@ -72,6 +72,14 @@ int gmg_set_system_matrix(gmg_context *ctx, int64_t n_rows, int64_t n_cols, cons
 /* mg_matrices[level] (include/step_50.h:168; filled src/step-50.cc:869-889, 930).         */
 int gmg_set_level_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
                          const int32_t *col, const double *val);
+/* mg_matrices[0] of the undivided lattice (Triangulation::subdivided_hyper_rectangle, src/step-50.cc:1526; assembled
+ * :869-889) FORMED ON THE DEVICE instead of handed over as CSR: nv[0..2] vertices per direction
+ * (>= 5), level DoFs numbered lexicographically (x fastest), Ke = the 8 x 8 cell matrix every cell adds (row-major, vertex a
+ * = bx + 2 by + 4 bz, as deal.II orders them), all faces Dirichlet (MGConstrainedDoFs boundary indices, :704-706: the row of
+ * a boundary DoF keeps sum |Ke[a][a]| on the diagonal, its couplings become stored zeros).  Values are the same bits
+ * gmg_set_level_matrix would receive (a vertex's cells added in cell order).  Level 0 only; not with a row-partitioned
+ * level 0.  The operator then serves y = A x (gmg_spmv) and the coarse CG.                                                */
+int gmg_set_level_matrix_lattice(gmg_context *ctx, int level, const int32_t nv[3], const double Ke[64]);
 /* mg_interface_matrices[level] (include/step_50.h:169; src/step-50.cc:892-925, 931); used as
  * both edge_out and edge_in, mg.set_edge_matrices(down, up) at :986.  Zeros may be pruned. */
 int gmg_set_edge_matrix(gmg_context *ctx, int level, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
@@ -175,6 +183,22 @@ int gmg_vec_allgather(gmg_context *ctx, int64_t n_global, double *dst_full, cons
 int gmg_set_halo_plan(gmg_context *ctx, int which, int n_neighbors, const int32_t *neighbor_rank,
                       const int32_t *send_count, const int32_t *send_idx, const int32_t *recv_count);
 
+/* mg_transfer.build_matrices(mg_dof_handler) (src/step-50.cc:957-958, inside the Solve timer) ON THE DEVICE: P_level (level
+ * -> level + 1, Q1 embedding, columns of coarse boundary DoFs dropped) and its transpose from the two levels' DoF tables
+ * instead of a host-built CSR (gmg_set_prolongation).  coarse_vertex[i] / fine_vertex[i]: the vertex of level DoF i as
+ * x | y << 21 | z << 42 in units of a lattice on which the fine level's vertices are `fine_spacing` apart (a power of two)
+ * and the coarse level's 2 * fine_spacing; coarse_boundary[i] = 1 for DoFs on the domain boundary (MGConstrainedDoFs,
+ * :704-706).  Rows come out in ascending column order, the transpose in ascending source-row order (the order of the
+ * reference's sequential Tvmult): identical to what gmg_set_prolongation receives / derives.  build_ms (may be NULL)
+ * returns the device time of the build.                                                                              */
+int gmg_build_transfer(gmg_context *ctx, int level, int dim, int64_t n_coarse, const uint64_t *coarse_vertex,
+                       const uint8_t *coarse_boundary, int64_t n_fine, const uint64_t *fine_vertex, uint64_t fine_spacing,
+                       double *build_ms);
+/* The CSR of P_level (transposed = 0) or of its transpose as the device holds it (for tests of gmg_build_transfer against
+ * the host-built operator): with rowptr == NULL only the sizes are returned.                                          */
+int gmg_get_transfer(gmg_context *ctx, int level, int transposed, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
+                     int64_t *rowptr, int32_t *col, double *val);
+
 /* ---- measurement -------------------------------------------------------------------- */
 typedef struct gmg_stats {
   int64_t coarse_solves;        /* calls of the coarse solver since the last reset           */
@@ -186,7 +210,7 @@ typedef struct gmg_stats {
   int64_t cgupd_samples;
   double cgupd_ms_total;
   int64_t coarse_variant;       /* 1 = fused (SpMV + direction update), 2 = unfused, of the last solve */
-  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) + 16 (row classes) */
+  int64_t spmv0_layout;         /* 0 = CSR row windows; else 1 (SELL-64) + 2 (8-bit value codes) + 4 (16-bit column offsets) + 8 (pattern-run kernel) + 16 (row classes) + 32 (plane-by-plane lattice kernel) + 64 (formed on the device: no CSR behind it) */
   int64_t spmv0_matrix_bytes;   /* bytes of the level-0 operator one SpMV streams in its device layout */
   int64_t spmv0_pattern_slices, spmv0_slices; /* slices served by a column pattern / all slices */
   int64_t coarse_enqueued;      /* coarse iterations enqueued, incl. those that returned at once after convergence */
@@ -197,6 +221,7 @@ typedef struct gmg_stats {
   int64_t sgs_substeps;         /* dependent steps those launches walked (the sweep is latency bound)                */
   int64_t sgs_stream_bytes;     /* record bytes they streamed                                                        */
   int64_t sgs_launches;         /* all SSOR sweep launches while profiling was on (every sample_every-th one is timed)  */
+  double build_matrices_ms;     /* device time of gmg_build_transfer calls since the last reset (the reference counts build_matrices in its Solve timer, :941-958) */
 } gmg_stats;
 int gmg_stats_reset(gmg_context *ctx);
 int gmg_stats_get(gmg_context *ctx, gmg_stats *out);

@@ -149,3 +149,66 @@ def test_cell_by_cell_numbering_of_the_host_side():
         assert bad.size == 0, (bad[:10], y[bad[:3]], ref[bad[:3]])
         c.close()
     p.close()
+
+
+@pytest.mark.parametrize("shape", [(5, 5, 5), (17, 9, 12), (45, 45, 45), (61, 37, 29)])
+def test_level0_formed_on_the_device_equals_the_csr_path(shape):
+    """gmg_set_level_matrix_lattice: the level-0 matrix formed on the device from (vertices per direction,
+    8 x 8 cell matrix) against the CSR the host assembles for the same lattice (src/step-50.cc:869-889 restated in
+    lattice_operator's sibling below: every cell adds Ke, boundary rows keep sum |Ke[a][a]|): products bit for bit, same
+    coarse-CG iteration count."""
+    nx, ny, nz = shape
+    h = 0.25
+    # Q1 Laplace cell matrix on a cube of edge h (the reference's K_e, SURVEY.md Appendix A.2), any symmetric 8 x 8 matrix would do
+    rng = np.random.default_rng(nx * 1000 + ny)
+    Ke = np.zeros((8, 8))
+    for a in range(8):
+        for b in range(8):
+            m = bin(a ^ b).count("1")
+            Ke[a, b] = h * (1.0 / 3.0, 0.0, -1.0 / 12.0, -1.0 / 12.0)[m]
+    Ke += 1e-3 * np.diag(rng.random(8))  # (break the symmetry between the vertices of a cell: the sums must follow the cell order)
+    # host-style assembly: cells in lexicographic order, every cell adds Ke; CSR pattern = all pairs sharing a cell
+    n = nx * ny * nz
+    bnd = np.zeros((nz, ny, nx), bool)
+    bnd[0], bnd[-1], bnd[:, 0], bnd[:, -1], bnd[:, :, 0], bnd[:, :, -1] = True, True, True, True, True, True
+    bnd = bnd.ravel()
+    dense = {}
+    import itertools
+    for cz, cy, cx in itertools.product(range(nz - 1), range(ny - 1), range(nx - 1)):
+        d = [cx + (a & 1) + nx * (cy + ((a >> 1) & 1)) + nx * ny * (cz + ((a >> 2) & 1)) for a in range(8)]
+        for a in range(8):
+            for b in range(8):
+                key = (d[a], d[b])
+                dense.setdefault(key, 0.0)
+            if bnd[d[a]]:
+                dense[(d[a], d[a])] += abs(Ke[a, a])
+            else:
+                for b in range(8):
+                    if not bnd[d[b]]:
+                        dense[(d[a], d[b])] += Ke[a, b]
+    keys = sorted(dense)
+    rows = np.array([k[0] for k in keys]); cols = np.array([k[1] for k in keys], dtype=np.int32)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp, rows + 1, 1)
+    m = SimpleNamespace(n_rows=n, n_cols=n, rowptr=np.cumsum(rp), col=cols, val=np.array([dense[k] for k in keys]), nnz=len(keys))
+    x = rng.standard_normal(n)
+    ref = go.spmv(m, x)
+    c = capi().Context(1)
+    c.set_level_matrix_lattice(0, shape, Ke)
+    assert int(c.stats().spmv0_layout) == 127  # every layout bit + 64: formed on the device
+    vx, vy = c.vector(n, x), c.vector(n, np.full(n, np.nan))
+    c.spmv(0, vy, vx)
+    y = vy.download()
+    bad = np.nonzero(~(y == ref))[0]
+    assert bad.size == 0, (shape, bad[:10], y[bad[:3]], ref[bad[:3]])
+    b = rng.standard_normal(n)
+    vb, vs = c.vector(n, b), c.vector(n)
+    it, res, rc = c.coarse_solve(vs, vb)
+    c2 = capi().Context(1)
+    c2.set_tuning(cg_variant=2)
+    c2.set_level_matrix(0, m)
+    vb2, vs2 = c2.vector(n, b), c2.vector(n)
+    it2, res2, rc2 = c2.coarse_solve(vs2, vb2)
+    assert rc == 0 and rc2 == 0 and it == it2
+    assert np.abs(vs.download() - vs2.download()).max() <= 1e-10 * np.abs(vs2.download()).max()
+    c.close(); c2.close()
