@@ -29,7 +29,7 @@ SYMBOLS = [
     "gmg_prolongate", "gmg_restrict_and_add", "gmg_cg_solve",
     "gmg_comm_unique_id", "gmg_comm_init", "gmg_comm_barrier", "gmg_comm_info", "gmg_set_halo_plan", "gmg_set_global_sizes", "gmg_partition_range",
     "gmg_vec_allgather",
-    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_option", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density",
+    "gmg_stats_reset", "gmg_stats_get", "gmg_set_profiling", "gmg_set_tuning", "gmg_set_option", "gmg_set_ssor_blocks", "gmg_calibrate_hbm", "gmg_charge_density", "gmg_get_charge_density", "gmg_rhs_assemble",
 ]
 
 

@@ -182,6 +182,9 @@ struct gmg_context {
   long long sgs_launch_no = 0;
   hipEvent_t timed_start = nullptr, timed_stop = nullptr;  // next launch carries these as its dispatch start / stop events
   gmg_stats stats{};
+  double *dens_dev = nullptr;  // charge densities kept on the device (gmg_charge_density with dens == NULL): [cells][nq]
+  int64_t dens_cells = 0;
+  int dens_nq = 0;
   Comm comm;
   bool dist = false;             // communicator initialised: level 0 + system rows are partitioned
   int64_t sys_global = 0, l0_global = 0;  // l0_global == 0 on a communicator: level 0 is replicated, only the outer CG is partitioned
@@ -2127,6 +2130,7 @@ int gmg_destroy(gmg_context *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   release_operators(ctx);  // (before the communicator: the shared direction vectors are unmapped collectively)
   if (ctx->peer_push_cnt) (void)hipFree(ctx->peer_push_cnt);
+  if (ctx->dens_dev) (void)hipFree(ctx->dens_dev);
   comm_destroy(ctx->comm);
   for (double *p : {ctx->part_a, ctx->part_b, ctx->scal_dev})
     if (p) (void)hipFree(p);
@@ -2824,6 +2828,7 @@ int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo,
   UP(d_bitems, bitems.data(), sizeof(int32_t) * bitems.size());
 #undef UP
   if (hipMalloc(&d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq) != hipSuccess) { cleanup(); return fail(ctx, GMG_ERR_HIP, "gmg_charge_density: out of memory"); }
+  if (ctx->dens_dev) { (void)hipFree(ctx->dens_dev); ctx->dens_dev = nullptr; ctx->dens_cells = 0; ctx->dens_nq = 0; }
   a.cell_lo = d_lo; a.cell_h = d_h; a.root_lo = d_root; a.root_h = root_h;
   a.atom_xyz = d_xyz; a.atom_q = d_q; a.n_atoms = (int)n_atoms;
   a.bin_lo0 = lo[0]; a.bin_lo1 = lo[1]; a.bin_lo2 = lo[2]; a.bin_size = bs;
@@ -2833,10 +2838,99 @@ int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo,
   a.qp = d_qp; a.nq = nq; a.n_cells = (int)n_cells; a.dens = d_dens;
   hipLaunchKernelGGL(charge_density_kernel, dim3((unsigned)((n_cells + 3) / 4)), dim3(kThreads), 0, ctx->stream, a);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(dens, d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && dens) e = hipMemcpyAsync(dens, d_dens, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && !dens) {  // the densities stay in HBM for gmg_rhs_assemble (gmg_get_charge_density copies them out on demand)
+    ctx->dens_dev = d_dens; ctx->dens_cells = n_cells; ctx->dens_nq = nq;
+    d_dens = nullptr;
+  }
   cleanup();
   if (e != hipSuccess) { ctx->err = std::string("gmg_charge_density: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
+  return GMG_OK;
+}
+
+int gmg_get_charge_density(gmg_context *ctx, int64_t n_cells, int nq, double *dens) {
+  if (!ctx || !dens) return GMG_ERR_INVALID;
+  if (!ctx->dens_dev || ctx->dens_cells != n_cells || ctx->dens_nq != nq) return fail(ctx, GMG_ERR_INVALID, "gmg_get_charge_density: no densities of this shape on the device");
+  HIPC(hipMemcpyAsync(dens, ctx->dens_dev, sizeof(double) * (size_t)n_cells * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return GMG_OK;
+}
+
+// assemble_system's right-hand side (src/step-50.cc:813-828) from densities that never left the device: per cell
+// F_i = sum_q phi_i(x_q) rho(x_q) w_q JxW (:813-820), the Dirichlet terms -K_ij g_j (:825-828) as a list of subtractions, and
+// the scatter into the DoFs as a per-DoF gather over the (cell, vertex) slots in the reference's cell order with the
+// hanging-node weights -- sequential per DoF: deterministic, no fp64 atomics, the same bits as the host loop.
+int gmg_rhs_assemble(gmg_context *ctx, int64_t n_cells, int nq, int dim, const double *shape, const double *weight, const uint8_t *cell_level,
+                     const double *jxw_of_level, int64_t n_terms, const int32_t *term_slot, const double *term_value, int64_t n_dofs,
+                     const int64_t *dof_ptr, const int32_t *entry_slot, const uint8_t *entry_coef, const double *coef_table, double *rhs) {
+  if (!ctx || n_cells < 0 || nq < 1 || nq > 512 || (dim != 2 && dim != 3) || !shape || !weight || !cell_level || !jxw_of_level || n_terms < 0 || n_dofs < 0 ||
+      !dof_ptr || !coef_table || !rhs)
+    return GMG_ERR_INVALID;
+  if (!ctx->dens_dev || ctx->dens_cells != n_cells || ctx->dens_nq != nq)
+    return fail(ctx, GMG_ERR_INVALID, "gmg_rhs_assemble: call gmg_charge_density(..., dens = NULL) for these cells first");
+  const int nv = 1 << dim;
+  const int64_t n_slots = n_cells * nv, n_ent = dof_ptr[n_dofs];
+  if (n_slots >= ((int64_t)1 << 31) || n_ent >= ((int64_t)1 << 31)) return fail(ctx, GMG_ERR_UNSUPPORTED, "gmg_rhs_assemble: more than 2^31 slots");
+  (void)hipSetDevice(ctx->device);
+  double *d_F = nullptr, *d_tv = nullptr;
+  uint8_t *d_lv = nullptr, *d_ec = nullptr;
+  int32_t *d_ts = nullptr, *d_es = nullptr, *d_ptr = nullptr;
+  RhsArgs a{};
+  auto cleanup = [&]() {
+    for (void *q : {(void *)d_F, (void *)d_tv, (void *)d_lv, (void *)d_ec, (void *)d_ts, (void *)d_es, (void *)d_ptr})
+      if (q) (void)hipFree(q);
+  };
+#define RHC(call) do { if ((call) != hipSuccess) { cleanup(); return fail(ctx, GMG_ERR_HIP, "gmg_rhs_assemble: " #call " failed"); } } while (0)
+  std::vector<int32_t> ptr32((size_t)n_dofs + 1);
+  for (int64_t i = 0; i <= n_dofs; ++i) {
+    if (i && dof_ptr[i] < dof_ptr[i - 1]) return fail(ctx, GMG_ERR_INVALID, "gmg_rhs_assemble: dof_ptr not monotone");
+    ptr32[(size_t)i] = (int32_t)dof_ptr[i];
+  }
+  for (int64_t e = 0; e < n_ent; ++e)
+    if (entry_slot[e] < 0 || entry_slot[e] >= n_slots) return fail(ctx, GMG_ERR_INVALID, "gmg_rhs_assemble: slot out of range");
+  for (int64_t t = 0; t < n_terms; ++t)
+    if (term_slot[t] < 0 || term_slot[t] >= n_slots || (t && term_slot[t] < term_slot[t - 1])) return fail(ctx, GMG_ERR_INVALID, "gmg_rhs_assemble: term slots must ascend inside the slot range");
+  RHC(hipMalloc(&d_F, sizeof(double) * (size_t)std::max<int64_t>(n_slots, 1)));
+  RHC(hipMalloc(&d_lv, (size_t)std::max<int64_t>(n_cells, 1)));
+  RHC(hipMalloc(&d_ptr, sizeof(int32_t) * ptr32.size()));
+  RHC(hipMalloc(&d_es, sizeof(int32_t) * (size_t)std::max<int64_t>(n_ent, 1)));
+  RHC(hipMalloc(&d_ec, (size_t)std::max<int64_t>(n_ent, 1)));
+  RHC(hipMalloc(&d_ts, sizeof(int32_t) * (size_t)std::max<int64_t>(n_terms, 1)));
+  RHC(hipMalloc(&d_tv, sizeof(double) * (size_t)std::max<int64_t>(n_terms, 1)));
+  if (n_cells) RHC(hipMemcpyAsync(d_lv, cell_level, (size_t)n_cells, hipMemcpyHostToDevice, ctx->stream));
+  RHC(hipMemcpyAsync(d_ptr, ptr32.data(), sizeof(int32_t) * ptr32.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (n_ent) {
+    RHC(hipMemcpyAsync(d_es, entry_slot, sizeof(int32_t) * (size_t)n_ent, hipMemcpyHostToDevice, ctx->stream));
+    RHC(hipMemcpyAsync(d_ec, entry_coef, (size_t)n_ent, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (n_terms) {
+    RHC(hipMemcpyAsync(d_ts, term_slot, sizeof(int32_t) * (size_t)n_terms, hipMemcpyHostToDevice, ctx->stream));
+    RHC(hipMemcpyAsync(d_tv, term_value, sizeof(double) * (size_t)n_terms, hipMemcpyHostToDevice, ctx->stream));
+  }
+  a.dens = ctx->dens_dev; a.n_cells = n_cells; a.nq = nq; a.nv = nv; a.cell_level = d_lv; a.F = d_F;
+  for (int q = 0; q < nq; ++q) {
+    a.weight[q] = weight[q];
+    for (int i = 0; i < nv; ++i) a.shape[q * 8 + i] = shape[q * nv + i];
+  }
+  for (int l = 0; l < 16; ++l) a.jxw[l] = jxw_of_level[l];
+  a.n_terms = n_terms; a.term_slot = d_ts; a.term_value = d_tv;
+  a.n_dofs = n_dofs; a.dof_ptr = d_ptr; a.entry_slot = d_es; a.entry_coef = d_ec; a.rhs = rhs;
+  for (int c = 0; c < 256; ++c) a.coef[c] = coef_table[c];
+  RhsArgs *d_a = nullptr;  // (the argument block is 39 KB: it travels through memory, not through the kernel-argument segment)
+  RHC(hipMalloc(&d_a, sizeof(RhsArgs)));
+  hipError_t e = hipMemcpyAsync(d_a, &a, sizeof(RhsArgs), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    if (n_cells) hipLaunchKernelGGL(rhs_cell_kernel, dim3(grid_for(n_cells)), dim3(kThreads), 0, ctx->stream, (const RhsArgs *)d_a);
+    if (n_terms) hipLaunchKernelGGL(rhs_terms_kernel, dim3(grid_for(n_terms)), dim3(kThreads), 0, ctx->stream, (const RhsArgs *)d_a);
+    if (n_dofs) hipLaunchKernelGGL(rhs_gather_kernel, dim3(grid_for(n_dofs)), dim3(kThreads), 0, ctx->stream, (const RhsArgs *)d_a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_a);
+#undef RHC
+  cleanup();
+  if (e != hipSuccess) { ctx->err = std::string("gmg_rhs_assemble: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
   return GMG_OK;
 }
 

@@ -1311,6 +1311,66 @@ __global__ __launch_bounds__(kThreads) void charge_density_kernel(DensityArgs a)
   }
 }
 
+
+// ---------------------------------------------------------------- right-hand side from device-resident densities
+// assemble_system's F (src/step-50.cc:813-828): per cell F_i = sum_q phi_i(x_q) rho(x_q) w_q JxW in the reference's
+// operation order, then the Dirichlet terms (F_slot -= K_ij g_j, one list entry per subtraction, applied in list order by
+// the thread that owns the slot's run), then per DoF the sum over its (cell, vertex) slots in cell order with the
+// constraint weights.  Everything sequential per output value: deterministic, the host loop's bits.
+struct RhsArgs {
+  const double *dens;  // [cells][nq]
+  int64_t n_cells;
+  int nq, nv;
+  const uint8_t *cell_level;
+  double shape[512 * 8];  // [q][i] (8 slots per q; 2D uses the first four); up to 8^3 quadrature points
+  double weight[512];
+  double jxw[16];        // by level
+  double *F;             // [cells][nv]
+  int64_t n_terms;
+  const int32_t *term_slot;  // ascending
+  const double *term_value;
+  int64_t n_dofs;
+  const int32_t *dof_ptr, *entry_slot;
+  const uint8_t *entry_coef;  // 0: the slot's F as it is; c > 0: coef[c] * F
+  double coef[256];
+  double *rhs;
+};
+__global__ __launch_bounds__(kThreads) void rhs_cell_kernel(const RhsArgs *ap) {
+  const RhsArgs &a = *ap;
+  for (int64_t c = (int64_t)blockIdx.x * kThreads + threadIdx.x; c < a.n_cells; c += (int64_t)gridDim.x * kThreads) {
+    const double jxw = a.jxw[a.cell_level[c] & 15];
+    double F[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < a.nq; ++q) {
+      const double d = a.dens[c * a.nq + q], w = a.weight[q];
+      for (int i = 0; i < a.nv; ++i) F[i] += a.shape[q * 8 + i] * d * w * jxw;
+    }
+    for (int i = 0; i < a.nv; ++i) a.F[c * a.nv + i] = F[i];
+  }
+}
+// the subtractions of one slot form a run in the list: the thread at the run's first entry applies all of them, in order
+__global__ __launch_bounds__(kThreads) void rhs_terms_kernel(const RhsArgs *ap) {
+  const RhsArgs &a = *ap;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < a.n_terms; t += (int64_t)gridDim.x * kThreads) {
+    const int32_t slot = a.term_slot[t];
+    if (t > 0 && a.term_slot[t - 1] == slot) continue;
+    double f = a.F[slot];
+    for (int64_t u = t; u < a.n_terms && a.term_slot[u] == slot; ++u) f -= a.term_value[u];
+    a.F[slot] = f;
+  }
+}
+__global__ __launch_bounds__(kThreads) void rhs_gather_kernel(const RhsArgs *ap) {
+  const RhsArgs &a = *ap;
+  for (int64_t d = (int64_t)blockIdx.x * kThreads + threadIdx.x; d < a.n_dofs; d += (int64_t)gridDim.x * kThreads) {
+    double acc = 0.0;
+    for (int32_t e = a.dof_ptr[d]; e < a.dof_ptr[d + 1]; ++e) {
+      const double f = a.F[a.entry_slot[e]];
+      const int c = a.entry_coef[e];
+      acc += c == 0 ? f : a.coef[c] * f;
+    }
+    a.rhs[d] = acc;
+  }
+}
+
 // ---------------------------------------------------------------- HBM calibration (measurement only)
 // Pure streaming read (16 B / lane, grid-stride) and copy: the ceiling the SpMV is compared with
 // on the device it actually runs on (bench.py reports it next to the 8 TB/s spec figure).

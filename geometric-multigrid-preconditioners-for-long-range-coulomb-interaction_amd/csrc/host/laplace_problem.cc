@@ -214,7 +214,9 @@ void ParameterReader::declare_parameters() {
             // as CSR (gmg_set_level_matrix_lattice; 3D constant-coefficient problems with a lexicographic, unpartitioned level 0)
             {"Level 0 matrix on device", "true"},
             // MGTransferPrebuilt::build_matrices on the device (gmg_build_transfer) instead of here + upload
-            {"Transfer matrices on device", "true"}};
+            {"Transfer matrices on device", "true"},
+            // the right-hand side integrated on the device from densities that stay there (gmg_rhs_assemble)
+            {"RHS on device", "true"}};
 }
 void ParameterReader::parse_input_from_string(const std::string &text) {
   std::istringstream in(text);
@@ -282,6 +284,7 @@ Parameters Parameters::from(const ParameterReader &prm) {  // src/main.cc:25-68
     throw std::runtime_error("Refinement estimator must be <Kelly + residual> or <Kelly>");
   p.level0_matrix_on_device = prm.get_bool("Level 0 matrix on device");
   p.transfer_on_device = prm.get_bool("Transfer matrices on device");
+  p.rhs_on_device = prm.get_bool("RHS on device");
   p.level0_numbering = prm.get("Level 0 numbering");
   if (p.level0_numbering != "lexicographic" && p.level0_numbering != "cell-wise")
     throw std::runtime_error("Level 0 numbering must be <lexicographic> or <cell-wise>");
@@ -693,6 +696,7 @@ void LaplaceProblem<dim>::compute_charge_densities() {
   const Quadrature<dim> quad((int)(par.degree + par.quadrature_degree_rhs));
   const size_t nq = quad.p.size();
   density_values_for_each_cell.assign(active_cells.size(), {});
+  densities_device_resident = false;
   if (densities_on_device && dim == 3) {
     // the same sums on the MI355X (gmg_charge_density), cell geometry in, rho out
     if (ensure_context() != GMG_OK) throw std::runtime_error("charge densities on the device: " + last_error);
@@ -711,10 +715,14 @@ void LaplaceProblem<dim>::compute_charge_densities() {
     }
     for (size_t q = 0; q < nq; ++q)
       for (int d = 0; d < 3; ++d) qp[3 * q + (size_t)d] = quad.p[q][(size_t)d];
+    // "RHS on device": the densities stay in HBM (dens = NULL) and gmg_rhs_assemble integrates them there; the host gets a
+    // copy only if something asks for it (HEAD's residual estimator, the rc_variation check vector): ensure_host_densities()
+    densities_device_resident = par.rhs_on_device;
     const int rc = gmg_charge_density(gmg, (int64_t)nc, lo.data(), hh.data(), rlo.data(), triangulation.h0, (int64_t)number_of_atoms,
                                       atom_positions.data(), charges.data(), par.r_c, par.nonzero_density_radius_parameter * par.r_c,
-                                      par.flag_rhs_assembly ? 1 : 0, (int)nq, qp.data(), dens.data());
+                                      par.flag_rhs_assembly ? 1 : 0, (int)nq, qp.data(), densities_device_resident ? nullptr : dens.data());
     if (rc != GMG_OK) throw std::runtime_error(std::string("gmg_charge_density: ") + gmg_last_error(gmg));
+    if (densities_device_resident) { density_values_for_each_cell.clear(); return; }
     for (size_t ci = 0; ci < nc; ++ci) density_values_for_each_cell[ci].assign(dens.begin() + (std::ptrdiff_t)(ci * nq), dens.begin() + (std::ptrdiff_t)((ci + 1) * nq));
     return;
   }
@@ -753,6 +761,17 @@ void LaplaceProblem<dim>::compute_charge_densities() {
       }
     }
   }
+}
+
+template <int dim>
+void LaplaceProblem<dim>::ensure_host_densities() {
+  if (!lammpsinput || !densities_device_resident || density_values_for_each_cell.size() == active_cells.size()) return;
+  const Quadrature<dim> quad((int)(par.degree + par.quadrature_degree_rhs));
+  const size_t nq = quad.p.size(), nc = active_cells.size();
+  std::vector<double> dens(nc * nq);
+  if (gmg_get_charge_density(gmg, (int64_t)nc, (int)nq, dens.data()) != GMG_OK) throw std::runtime_error(std::string("gmg_get_charge_density: ") + gmg_last_error(gmg));
+  density_values_for_each_cell.assign(nc, {});
+  for (size_t ci = 0; ci < nc; ++ci) density_values_for_each_cell[ci].assign(dens.begin() + (std::ptrdiff_t)(ci * nq), dens.begin() + (std::ptrdiff_t)((ci + 1) * nq));
 }
 
 template <int dim>
@@ -816,6 +835,21 @@ void LaplaceProblem<dim>::assemble_system() {
   }
   system_matrix = pattern_from_cells(n, cptr, citems);
   system_rhs.assign((size_t)n, 0.0);
+  // "RHS on device": the cell loop records WHERE every F_i goes (DoF, slot = cell * 2^dim + i, weight) and which Dirichlet
+  // terms it loses instead of forming F from densities the host does not have; gmg_rhs_assemble does the arithmetic
+  const bool rhs_dev = lammpsinput && densities_device_resident;
+  std::vector<int32_t> plan_dof, plan_slot, term_slot;
+  std::vector<uint8_t> plan_code;
+  std::vector<double> term_value, coef_table(256, 0.0);
+  int n_codes = 1;  // code 0: the slot's value as it is
+  auto code_of = [&](double w) -> int {
+    for (int c = 1; c < n_codes; ++c)
+      if (coef_table[(size_t)c] == w) return c;
+    if (n_codes >= 256) throw std::runtime_error("RHS on device: more than 255 distinct constraint weights");
+    coef_table[(size_t)n_codes] = w;
+    return n_codes++;
+  };
+  if (rhs_dev) { plan_dof.reserve(active_cells.size() * nv); plan_slot.reserve(active_cells.size() * nv); plan_code.reserve(active_cells.size() * nv); }
 
   double Kc[nv][nv];
   if (constant_coef) {
@@ -839,7 +873,7 @@ void LaplaceProblem<dim>::assemble_system() {
     double F[nv];
     for (int i = 0; i < nv; ++i) F[i] = 0;
     const double jxw = std::pow(h, dim);
-    for (size_t q = 0; q < q_rhs.p.size(); ++q) {
+    for (size_t q = 0; q < q_rhs.p.size() && !rhs_dev; ++q) {
       double dens;
       if (lammpsinput) dens = density_values_for_each_cell[ci][q];
       else {
@@ -859,11 +893,20 @@ void LaplaceProblem<dim>::assemble_system() {
     }
     for (int i = 0; i < nv; ++i) {
       double Fi = F[i];
+      const int32_t slot = (int32_t)(ci * nv + (size_t)i);
       for (int j = 0; j < nv; ++j)
-        if (line[j] && line[j]->inhomogeneity != 0.0) Fi -= K[i][j] * line[j]->inhomogeneity;
+        if (line[j] && line[j]->inhomogeneity != 0.0) {
+          if (rhs_dev) { term_slot.push_back(slot); term_value.push_back(K[i][j] * line[j]->inhomogeneity); }
+          else Fi -= K[i][j] * line[j]->inhomogeneity;
+        }
       if (line[i]) {
         system_matrix.add(dofs[i], dofs[i], std::fabs(K[i][i]));
-        for (auto &ri : line[i]->entries) system_rhs[(size_t)ri.first] += ri.second * Fi;
+        for (auto &ri : line[i]->entries) {
+          if (rhs_dev) { plan_dof.push_back(ri.first); plan_slot.push_back(slot); plan_code.push_back((uint8_t)code_of(ri.second)); }
+          else system_rhs[(size_t)ri.first] += ri.second * Fi;
+        }
+      } else if (rhs_dev) {
+        plan_dof.push_back(dofs[i]); plan_slot.push_back(slot); plan_code.push_back(0);
       } else {
         system_rhs[(size_t)dofs[i]] += Fi;
       }
@@ -881,6 +924,39 @@ void LaplaceProblem<dim>::assemble_system() {
         }
       }
     }
+  }
+  if (rhs_dev) {
+    // per-DoF gather lists in the order the loop above would have added (a stable counting sort by DoF)
+    std::vector<int64_t> dof_ptr((size_t)n + 1, 0);
+    for (int32_t d : plan_dof) dof_ptr[(size_t)d + 1]++;
+    for (int64_t i = 0; i < n; ++i) dof_ptr[(size_t)i + 1] += dof_ptr[(size_t)i];
+    std::vector<int32_t> entry_slot(plan_dof.size());
+    std::vector<uint8_t> entry_code(plan_dof.size());
+    {
+      std::vector<int64_t> pos(dof_ptr.begin(), dof_ptr.end() - 1);
+      for (size_t e = 0; e < plan_dof.size(); ++e) {
+        const int64_t q = pos[(size_t)plan_dof[e]]++;
+        entry_slot[(size_t)q] = plan_slot[e];
+        entry_code[(size_t)q] = plan_code[e];
+      }
+    }
+    std::vector<uint8_t> cell_level(active_cells.size());
+    for (size_t ci = 0; ci < active_cells.size(); ++ci) cell_level[ci] = (uint8_t)active_cells[ci].level;
+    double jxw_of_level[16];
+    for (int l = 0; l < 16; ++l) jxw_of_level[l] = std::pow(triangulation.cell_size(l), dim);
+    std::vector<double> shape(q_rhs.p.size() * nv), weight(q_rhs.p.size());
+    for (size_t q = 0; q < q_rhs.p.size(); ++q) {
+      weight[q] = q_rhs.w[q];
+      for (int i = 0; i < nv; ++i) shape[q * nv + (size_t)i] = q_rhs.shape[q][(size_t)i];
+    }
+    double *d_out = nullptr;
+    auto chk = [&](int rc, const char *what) { if (rc != GMG_OK) throw std::runtime_error(std::string(what) + ": " + gmg_last_error(gmg)); };
+    chk(gmg_vec_alloc(gmg, n, &d_out), "gmg_vec_alloc");
+    chk(gmg_rhs_assemble(gmg, (int64_t)active_cells.size(), (int)q_rhs.p.size(), dim, shape.data(), weight.data(), cell_level.data(), jxw_of_level,
+                         (int64_t)term_slot.size(), term_slot.data(), term_value.data(), n, dof_ptr.data(), entry_slot.data(), entry_code.data(),
+                         coef_table.data(), d_out), "gmg_rhs_assemble");
+    chk(gmg_vec_download(gmg, system_rhs.data(), d_out, n), "gmg_vec_download");
+    gmg_vec_free(gmg, d_out);
   }
 }
 
@@ -1487,6 +1563,7 @@ template <int dim>
 std::vector<double> LaplaceProblem<dim>::total_charge_density_vector() const {
   constexpr int nv = 1 << dim;
   std::vector<double> t(vertex_of_dof.size(), 0.0);
+  const_cast<LaplaceProblem<dim> *>(this)->ensure_host_densities();
   if (!lammpsinput || density_values_for_each_cell.size() != active_cells.size()) return t;
   const Quadrature<dim> q_rhs((int)(par.degree + par.quadrature_degree_rhs));
   for (size_t ci = 0; ci < active_cells.size(); ++ci) {

@@ -65,6 +65,7 @@ struct Parameters {
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
   std::string refinement_estimator = "Kelly + residual";  // HEAD (:1040-1089) | "Kelly": the indicator of the older cluster runs
+  bool rhs_on_device = true;            // gmg_rhs_assemble: F integrated on the device from densities that stay there
   bool transfer_on_device = true;       // gmg_build_transfer instead of building P_l here and uploading it
   bool level0_matrix_on_device = true;  // gmg_set_level_matrix_lattice instead of assembling + uploading level 0 (3D, constant coefficient, lexicographic, unpartitioned)
   std::string level0_numbering = "lexicographic";  // lexicographic | cell-wise (deal.II's first-touch order): level 0 carries no smoother
@@ -102,6 +103,7 @@ class LaplaceProblem {
   void setup_system(unsigned int cycle);                                 // :646-732
   void rhs_assembly_optimization();                                      // :260-306
   void compute_charge_densities();                                       // :509-575
+  void ensure_host_densities();                                          // copy device-resident densities out when the host needs them
   void compute_moments();                                                // :577-644
   void assemble_system();                                                // :735-833
   void assemble_multigrid();                                             // :835-933
@@ -143,6 +145,7 @@ class LaplaceProblem {
   gmg_context *gmg = nullptr;
   bool operators_uploaded = false, densities_on_device = false;
   bool solve_on_device_requested = false, level0_on_device = false, transfer_on_device = false;
+  bool densities_device_resident = false;  // compute_charge_densities left them in HBM for gmg_rhs_assemble
   double build_matrices_ms = 0.0;  // device time of gmg_build_transfer for the current cycle's operators
   std::string last_error;
   // one process per GPU (the reference: one MPI rank per subdomain, src/main.cc:8); the host

@@ -80,6 +80,7 @@ def prm_text(**kw) -> str:
         "level0_numbering": ("Misc", "Level 0 numbering"),
         "level0_on_device": ("Misc", "Level 0 matrix on device"),
         "transfer_on_device": ("Misc", "Transfer matrices on device"),
+        "rhs_on_device": ("Misc", "RHS on device"),
     }
     sections = {}
     for k, v in kw.items():

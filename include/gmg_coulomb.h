@@ -142,10 +142,25 @@ int gmg_cg_solve(gmg_context *ctx, double *x, const double *b, double rel_tol, i
  * quadrature points, summed over the atoms closer than `cutoff` to any vertex of the cell's
  * ROOT cell (use_lists != 0; children inherit the parent's list, :441-450) or over all atoms.
  * Host arrays in, host array out (dens[n_cells * nq], incl. the factor 4 pi of :522).       */
+/* dens == NULL keeps the densities on the device for gmg_rhs_assemble (gmg_get_charge_density copies them out on demand).   */
 int gmg_charge_density(gmg_context *ctx, int64_t n_cells, const double *cell_lo, const double *cell_h,
                        const double *root_lo, double root_h, int64_t n_atoms, const double *atom_xyz,
                        const double *atom_q, double r_c, double cutoff, int use_lists, int nq,
                        const double *quadrature_points, double *dens);
+/* the densities gmg_charge_density kept on the device (dens == NULL), copied out: [n_cells * nq]                        */
+int gmg_get_charge_density(gmg_context *ctx, int64_t n_cells, int nq, double *dens);
+/* The right-hand side of assemble_system (src/step-50.cc:813-828) from the densities the preceding
+ * gmg_charge_density(..., dens = NULL) left on the device -- they never cross PCIe:
+ *   per cell   F_i = sum_q shape[q][i] * rho_q * weight[q] * jxw_of_level[level]      (:813-820, the reference's operand order)
+ *   Dirichlet  F[term_slot[t]] -= term_value[t], t ascending   (term_value = K_ij g_j, :825-828; slots ascending in the list)
+ *   per DoF d  rhs[d] = sum over e in [dof_ptr[d], dof_ptr[d+1]) of (entry_coef[e] == 0 ? F[slot] : coef_table[code] * F[slot])
+ * with slot = cell * 2^dim + vertex, the entries of a DoF in the order the reference's cell loop adds them
+ * (distribute_local_to_global: hanging-node rows contribute to their masters with the constraint weight).  Every output
+ * value is one sequential sum: deterministic, no atomics.  shape: [nq][2^dim]; cell_level: [n_cells]; rhs: device vector.  */
+int gmg_rhs_assemble(gmg_context *ctx, int64_t n_cells, int nq, int dim, const double *shape, const double *weight,
+                     const uint8_t *cell_level, const double *jxw_of_level /* [16] */, int64_t n_terms, const int32_t *term_slot,
+                     const double *term_value, int64_t n_dofs, const int64_t *dof_ptr, const int32_t *entry_slot,
+                     const uint8_t *entry_coef, const double *coef_table /* [256] */, double *rhs);
 
 /* ---- distributed (one process per GPU, RCCL over xGMI) ------------------------------ */
 #define GMG_UNIQUE_ID_BYTES 128

@@ -17,7 +17,7 @@ from oracle import gmg_oracle as go
 S = pkg.step50
 nacl = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 go.set_threads(8)
-p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous",
+p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous", rhs_on_device=False,
                          cycles=2, r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="SSOR"))
 p.set_nacl_atoms(nacl)
 p.run_cycle(0, on_device=False)
