@@ -32,3 +32,18 @@ def rel_close(a, b, digits):
     if b == 0:
         return abs(a) < 10.0 ** (-digits)
     return abs(a - b) <= 0.6 * 10.0 ** (-digits + 1) * abs(b)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _device_context_first(request):
+    """On a GPU box the test process opens its device context before any test starts rank processes of its own (the
+    multi-rank tests run 2-3 children on the same GPU; a parent that first touches the device after several such groups was
+    once refused a context).  No GPU: nothing happens."""
+    if "not gpu" in (request.config.getoption("-m") or ""):
+        return
+    try:
+        from gpu_util import capi
+
+        capi().Context(1).close()
+    except Exception:
+        pass
