@@ -65,6 +65,8 @@ struct Parameters {
   bool device_resident_outer_cg = false;  // true: gmg_cg_solve instead of the host SolverCG
   std::string partition_level0 = "auto";  // one process per GPU: auto | always | never
   std::string refinement_estimator = "Kelly + residual";  // HEAD (:1040-1089) | "Kelly": the indicator of the older cluster runs
+  double short_range_cutoff = 0.0;        // in smoothing lengths; 0: all pairs (the reference)
+  bool energy_for_large_systems = false;  // evaluate the energy also for >= 300 atoms (needs the cutoff; the reference skips it, :1554)
   bool rhs_on_device = true;            // gmg_rhs_assemble: F integrated on the device from densities that stay there
   bool transfer_on_device = true;       // gmg_build_transfer instead of building P_l here and uploading it
   bool level0_matrix_on_device = true;  // gmg_set_level_matrix_lattice instead of assembling + uploading level 0 (3D, constant coefficient, lexicographic, unpartitioned)
@@ -168,6 +170,8 @@ class LaplaceProblem {
   std::vector<uint64_t> vertex_of_dof;
   std::vector<std::unordered_map<uint64_t, int32_t>> level_dof_of_vertex;
   std::vector<std::vector<uint64_t>> level_vertex_of_dof;
+  std::vector<int32_t> active_cell_dof_table;                 // [active cell][vertex]: the DoFs of every active cell (cell_dofs)
+  std::vector<std::vector<int32_t>> level_cell_dof_table;     // [level][cell][vertex] (level_cell_dofs)
   // constraints (hanging nodes + Dirichlet), resolved: masters are unconstrained DoFs
   struct ConstraintLine { std::vector<std::pair<int32_t, double>> entries; double inhomogeneity = 0; bool hanging = false; };
   std::vector<int32_t> constraint_of_dof;  // -1 = unconstrained

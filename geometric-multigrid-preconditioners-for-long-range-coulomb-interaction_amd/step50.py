@@ -81,6 +81,8 @@ def prm_text(**kw) -> str:
         "level0_on_device": ("Misc", "Level 0 matrix on device"),
         "transfer_on_device": ("Misc", "Transfer matrices on device"),
         "rhs_on_device": ("Misc", "RHS on device"),
+        "short_range_cutoff": ("Misc", "Short-range cutoff in smoothing lengths"),
+        "energy_for_large_systems": ("Misc", "Energy for large systems"),
     }
     sections = {}
     for k, v in kw.items():

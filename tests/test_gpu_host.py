@@ -166,3 +166,30 @@ def test_rhs_cutoff_lists_on_device_match_reference_error_table(golden, golden_d
     from test_host import check_rc_variation
 
     check_rc_variation(golden, golden_dir, on_device=True)
+
+
+def test_short_range_energy_with_cutoff_and_for_large_systems(golden_dir):
+    """SURVEY 8(f) N3, second half: the erfc pair sum over the pairs within 6 smoothing lengths (cell bins) equals the
+    reference's all-pairs sum (src/step-50.cc:1325-1332) to the last digits on 216 atoms, and lets the energy be evaluated
+    for 1000 atoms, which the reference skips (number_of_atoms < 300, :1554)."""
+    S = pkg().step50
+
+    def run(nacl, **kw):
+        p = S.Problem(S.prm_text(left=0, right=float(nacl), mesh_size=0.25, vacuum=10, problem="GaussianCharges", dim=3, bc="Inhomogeneous", cycles=1,
+                                 r_c=0.5, cutoff=3.5, rhs_optimization=True, quad_rhs=1, global_refinement=0, smoother="Jacobi", **kw))
+        p.set_nacl_atoms(nacl)
+        r = p.run_cycle(0, on_device=True)
+        p.close()
+        return r
+
+    a, b = run(3), run(3, short_range_cutoff=6.0)
+    assert a["has_energy"] and b["has_energy"]
+    assert abs(a["energy_short"] - b["energy_short"]) <= 1e-13 * abs(a["energy_short"])
+    assert abs(a["energy_total"] - b["energy_total"]) <= 1e-13 * abs(a["energy_total"])
+    assert a["energy_fe_long"] == b["energy_fe_long"] and a["energy_analytical"] == b["energy_analytical"]
+    big = run(5)
+    assert not big["has_energy"]  # the reference's gate
+    big = run(5, short_range_cutoff=6.0, energy_for_large_systems=True)
+    assert big["has_energy"] and np.isfinite(big["energy_total"]) and big["energy_short"] < 0.0
+    # NaCl lattice: the short-ranged energy per ion of 1000 atoms is that of 216 atoms up to the surface share (measured: 5.1 %)
+    assert abs(big["energy_short"] / 1000 - a["energy_short"] / 216) <= 0.10 * abs(a["energy_short"] / 216)
