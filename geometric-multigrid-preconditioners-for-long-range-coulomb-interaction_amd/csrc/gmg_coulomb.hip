@@ -10,6 +10,7 @@
 #include "gmg_device.hpp"
 #include "gmg_sgs.hpp"
 #include "gmg_sgs_phase.hpp"
+#include "gmg_sgs_dep.hpp"
 #ifdef GMG_EXPERIMENTS
 #include "gmg_sgs_chain.hpp"  // hand-over through an LDS word instead of s_barrier: measured slower, kept as an experiment
 #endif
@@ -95,6 +96,7 @@ struct SgsPlan {
   int64_t w_stage_len = 0;
   // four-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
   bool phased = false;
+  bool dep = false;  // records laid out for gmg_sgs_dep.hpp (field-major, late = updated within the last three steps)
   PhRange *p_ranges = nullptr;
   uint4 *p_blk_tab = nullptr;
   std::vector<PhRange> host_pranges;
@@ -157,7 +159,7 @@ struct gmg_context {
   int coarse_chunk = 0;
   // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
-  bool sgs_disable_wave = false, sgs_disable_phase = false, sgs_chain = false, debug_upload = false, sgs_profile = false;
+  bool sgs_disable_wave = false, sgs_disable_phase = false, sgs_chain = false, sgs_dep = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
   int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
   bool sgs_phase_nocascade = false;  // every step gathers all T1 slots of its shape (comparison)
@@ -1058,7 +1060,27 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
         SgsPhaseArgs q{};
         q.ranges = L.sgs.p_ranges; q.blk_tab = L.sgs.p_blk_tab; q.block_rng = p.block_rng; q.block0 = p.block0; q.stream = p.stream; q.ws_ci = p.ws_ci; q.ci_row = p.ci_row;
         q.ycur = p.ycur; q.y = p.y; q.omega = p.omega; q.y_slots = p.y_slots; q.prof = nullptr;
-        if (ctx->sgs_phase_profile > 0 && n_ranks == 1) {  // (several ranks: the option is refused in gmg_set_option; the all-gather below must run)
+        if (ctx->sgs_phase_profile > 0 && n_ranks == 1 && L.sgs.dep) {
+          // diagnostics of the one-dependent-wave sweep: per range, cycles of every wave and how many of them it waited
+          const size_t nr = (size_t)L.sgs.w_n_ranges;
+          unsigned long long *d = nullptr;
+          std::vector<unsigned long long> h(12 * nr, 0);
+          HIPC(hipMalloc(&d, sizeof(unsigned long long) * 12 * nr));
+          q.prof = d;
+          hipLaunchKernelGGL(sgs_dep_kernel, dim3(nbl), dim3(kDpThreads), lds, ctx->stream, q, ctx->sgs_abort);
+          hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+          (void)hipFree(d);
+          if (e != hipSuccess) { ctx->err = std::string("SSOR sweep profile: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
+          if (L.sgs.w_steps > 1000 && nbl == 1)
+            for (size_t i = 0; i < nr; ++i) {
+              const PhRange &P = L.sgs.host_pranges[i];
+              std::fprintf(stderr, "[gmg]   %s steps %4d | cycles/step %7.1f | dependent wave waited %5.1f %% | prep waves waited %5.1f %% %5.1f %% %5.1f %%\n", P.backward ? "bwd" : "fwd",
+                           P.n_steps, (double)h[12 * i] / std::max(1, P.n_steps), 100.0 * h[12 * i + 1] / std::max<double>(1, h[12 * i]),
+                           100.0 * h[12 * i + 3] / std::max<double>(1, h[12 * i + 2]), 100.0 * h[12 * i + 5] / std::max<double>(1, h[12 * i + 4]),
+                           100.0 * h[12 * i + 7] / std::max<double>(1, h[12 * i + 6]));
+            }
+        } else if (ctx->sgs_phase_profile > 0 && n_ranks == 1 && !L.sgs.dep) {  // (several ranks: the option is refused in gmg_set_option; the all-gather below must run)
           // the instrumented variant of the sweep (same arithmetic, same results, s_memtime around every phase); the
           // launch falls through to the common tail like the production one
           const size_t nr = (size_t)L.sgs.w_n_ranges;
@@ -1084,6 +1106,14 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
                            (double)h[12 * i] / std::max(1, P.n_steps), h[12 * i + 2] + h[12 * i + 3], h[12 * i + 4] / turns, h[12 * i + 5] / turns, h[12 * i + 6] / turns, h[12 * i + 7] / turns,
                            h[12 * i + 8] / turns, h[12 * i + 9] / turns);
             }
+          }
+        } else
+        if (L.sgs.dep) {
+          if (ctx->timed_start) {  // (two kernel arguments: the one-argument launch_timed does not fit)
+            hipExtLaunchKernelGGL(sgs_dep_kernel, dim3(nbl), dim3(kDpThreads), (std::uint32_t)lds, ctx->stream, ctx->timed_start, ctx->timed_stop, 0u, q, ctx->sgs_abort);
+            ctx->timed_start = ctx->timed_stop = nullptr;
+          } else {
+            hipLaunchKernelGGL(sgs_dep_kernel, dim3(nbl), dim3(kDpThreads), lds, ctx->stream, q, ctx->sgs_abort);
           }
         } else
 #ifdef GMG_EXPERIMENTS
@@ -1457,7 +1487,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   if (ph) {
     for (int64_t i = 0; i < n && ph; ++i) ph = rp[i + 1] - rp[i] <= 2 * kPhMaxEntries;  // (cheap pre-check; the exact one is per range)
   }
-  const int y_max = ph ? kPhYSlots : kSwYSlots;
+  const bool dep = ph && ctx->sgs_dep;  // one dependent wave + three preparing waves (gmg_sgs_dep.hpp)
+  const int late_steps = dep ? kDpLate : 1;
+  const int y_max = dep ? kDpYSlots : ph ? kPhYSlots : kSwYSlots;
   int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : y_max;
   y_cap = std::max(64, std::min(y_cap, y_max)) & ~1;
   std::vector<PhRange> pranges;
@@ -1663,7 +1695,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               for (int32_t k = prp[(size_t)i]; k < prp[(size_t)i + 1]; ++k) {
                 const int c = pcol[(size_t)k];
                 if (!in_dir(i, c)) continue;
-                if (c != i && upd_stamp[(size_t)c] == stamp_id && step_of[(size_t)c] == (int32_t)(st - s0) - 1) {
+                if (c != i && upd_stamp[(size_t)c] == stamp_id && step_of[(size_t)c] >= (int32_t)(st - s0) - late_steps && step_of[(size_t)c] < (int32_t)(st - s0)) {
                   if (first_late < 0) first_late = ne;
                   last_late = ne;
                 }
@@ -1692,14 +1724,15 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               for (int g = 0; g <= 3; ++g)
                 for (int l1 = 4; l1 <= 28; l1 += 4)
                   for (int l2 = 0; l2 <= 24; l2 += 8) {
-                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
+                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0) || (dep && l1 > kDpMaxL1)) continue;
                     bool ok = true;
                     for (int u = 0; u < nr && ok; ++u) ok = fits(cut[c0 + (size_t)u], g, l1, l2, nullptr, nullptr);
                     if (!ok) continue;
                     const int ent = 8 * g + l1 + l2;
                     const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + (double)nr * ph_stride(g, l1 + l2)) / 1024.0,
                                  p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
-                    const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    // (dep: the dependent wave's step is what counts -- ~20 cycles per T1 slot, ~8 per T2 add; the rest is the prep waves')
+                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
                     if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
                   }
               if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1719,14 +1752,14 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               for (int g = 0; g <= 3; ++g)
                 for (int l1 = 4; l1 <= 28; l1 += 4)
                   for (int l2 = 0; l2 <= 24; l2 += 8) {
-                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0)) continue;
+                    if (!ph_shape_ok(g, l1, l2) || (ctx->sgs_phase_nosplit && l2 > 0) || (dep && l1 > kDpMaxL1)) continue;
                     bool ok = true;
                     for (size_t u = cpos[q0]; u < cpos[q1] && ok; ++u) ok = fits(cut[u], g, l1, l2, nullptr, nullptr);
                     if (!ok) continue;
                     const int ent = 8 * g + l1 + l2;
                     const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + avg_rows * ph_stride(g, l1 + l2)) / 1024.0,
                                  p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
-                    const double cost = std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
                     if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
                   }
               if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1761,10 +1794,14 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             for (int u = 0; u < S.nrows; ++u) {
               const int i = seq[(size_t)(S.first + u)];
               const int32_t ci = row_ci[(size_t)(rb + i)];
-              char *rec = blk + 16 + (size_t)u * pstride;
-              const int64_t rec_pos = base + off + 16 + (int64_t)u * pstride;
+              // four-wave sweep: records lane-major (one row's fields together); dep: FIELD-major -- unit k (16 bytes) of row u at
+              // block + 16 + (k * nrows + u) * 16, so that a preparing wave reads a field of all rows with one coalesced load
+              alignas(16) char rec_tmp[32 + 96 * 3 + 12 * kPhMaxEntries + 32];
+              char *rec = dep ? rec_tmp : blk + 16 + (size_t)u * pstride;
+              const int64_t rec_pos = dep ? base + off + 16 + (int64_t)u * 16 : base + off + 16 + (int64_t)u * pstride;
+              const int64_t pre_pos = dep ? base + off + 16 + ((int64_t)S.nrows + u) * 16 : rec_pos + 16;
               (dir == 0 ? rpos_f : rpos_b)[(size_t)ci] = (int32_t)(rec_pos / 8);
-              if (dir == 1) prefix_pos[(size_t)i] = (int32_t)(rec_pos / 8 + 2);
+              if (dir == 1) prefix_pos[(size_t)i] = (int32_t)(pre_pos / 8);
               double *f = reinterpret_cast<double *>(rec);
               uint32_t *wv = reinterpret_cast<uint32_t *>(rec);
               const uint32_t my = (uint32_t)slot_of[(size_t)i] * 8u;
@@ -1791,6 +1828,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                 else { tv[L1r + e - h1] = pval[(size_t)k]; ta[L1r + e - h1] = ad; }
                 ++e;
               }
+              if (dep)
+                for (int k = 0; k < (32 + 96 * Gr + 12 * Lr) / 16; ++k) std::memcpy(blk + 16 + ((size_t)k * S.nrows + (size_t)u) * 16, rec_tmp + 16 * k, 16);
               ++tix;
             }
             off += (raw + 15) / 16 * 16;
@@ -1938,7 +1977,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     }
   }
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = ph ? y_slots * 8 + kPhWaves * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
+  G.w_lds_bytes = dep ? y_slots * 8 + kDpSlots * ((kDpSlotBytes + 15) / 16 * 16) + kDpFlagBytes : ph ? y_slots * 8 + kPhWaves * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
+  G.dep = dep;
   G.w_n_ranges = (int)(ph ? pranges.size() : ranges.size());
   G.phased = ph;
   G.host_pranges = pranges;
@@ -1948,6 +1988,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPC(hipFuncSetAttribute((const void *)sgs_dep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef GMG_EXPERIMENTS
   HIPC(hipFuncSetAttribute((const void *)sgs_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
@@ -1955,6 +1996,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   hipFuncAttributes fa{};
   HIPC(hipFuncGetAttributes(&fa, ph ? (const void *)sgs_phase_kernel : (const void *)sgs_wave_kernel<false>));
   G.wave = fa.sharedSizeBytes == 0;
+  if (dep) {
+    HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_dep_kernel));
+    G.wave = G.wave && fa.sharedSizeBytes == 0;
+  }
 #ifdef GMG_EXPERIMENTS
   if (ph) {
     HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_chain_kernel));
@@ -3100,6 +3145,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_y_slots") ctx->sgs_y_slots = (int)value;
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
+  else if (k == "sgs_dep") ctx->sgs_dep = on;
   else if (k == "sgs_chain") {
 #ifndef GMG_EXPERIMENTS
     if (on) return fail(ctx, GMG_ERR_UNSUPPORTED, "sgs_chain needs a -DGMG_EXPERIMENTS build (tools/build_experiments.sh)");

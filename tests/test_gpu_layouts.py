@@ -120,9 +120,10 @@ def _random_sparse(n, per_row, rng, reach):
     return csr(n, n, rows)
 
 
+@pytest.mark.parametrize("sweep", ["phase", "dep"])
 @pytest.mark.parametrize("blocks", [1, 4])
 @pytest.mark.parametrize("shape", ["chain", "wide-stages", "wide-rows", "scattered"])
-def test_ssor_on_synthetic_dependency_shapes(shape, blocks):
+def test_ssor_on_synthetic_dependency_shapes(shape, blocks, sweep):
     """The SSOR sweep on operators whose dependency graphs stress the four-wave sweep (gmg_sgs_phase.hpp) in ways the mesh
     hierarchies do not, bit for bit against the oracle: a band of 27 consecutive columns (every stage is ONE row, every
     lower neighbour is late), a sparse operator with hundreds of independent rows per stage (stages cut into steps of 32
@@ -145,6 +146,8 @@ def test_ssor_on_synthetic_dependency_shapes(shape, blocks):
                            copy_global=[np.zeros(0, dtype=np.int32), idx], copy_level=[np.zeros(0, dtype=np.int32), idx])
     c = capi().Context(2)
     c.set_tuning(ssor_blocks=blocks)
+    if sweep == "dep":  # one dependent wave fed by three preparing waves (gmg_sgs_dep.hpp)
+        c.set_option("sgs_dep", 1)
     c.load_hierarchy(hier)
     c.set_smoother(capi().SSOR, 0.5, 2)
     mg = go.OracleMG(hier, smoother=go.SSOR, omega=0.5, steps=2, ssor_blocks=blocks)

@@ -238,6 +238,7 @@ def test_single_rank_communicator_path(hier45):
 
 
 @pytest.mark.parametrize("blocks,variant", [(1, "phase"), (3, "phase"), (16, "phase"), (1, "phase-ranges"), (3, "phase-ranges"), (1, "phase-nosplit"), (3, "phase-nosplit"), (1, "wave"), (3, "wave"), (16, "wave"),
+                                            (1, "dep"), (3, "dep"), (16, "dep"), (1, "dep-ranges"), (3, "dep-ranges"),
                                             (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
 def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the device
@@ -253,6 +254,8 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     c.set_tuning(ssor_blocks=blocks)
     if variant in ("wave", "ranges"):
         c.set_option("sgs_disable_phase", 1)
+    if variant.startswith("dep"):
+        c.set_option("sgs_dep", 1)
     if variant == "phase-nosplit":
         c.set_option("sgs_phase_nosplit", 1)
     if variant.endswith("ranges"):
