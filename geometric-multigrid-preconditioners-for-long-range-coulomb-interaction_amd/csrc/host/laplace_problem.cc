@@ -19,6 +19,16 @@
 
 namespace step50 {
 
+// STEP50_TIMING=2: wall time of the pieces of a host phase on stderr (since the previous call; nullptr restarts the clock)
+void sublap(const char *what) {
+  static const bool on = std::getenv("STEP50_TIMING") != nullptr && std::atoi(std::getenv("STEP50_TIMING")) >= 2;
+  static auto t_last = std::chrono::steady_clock::now();
+  if (!on) return;
+  const auto now = std::chrono::steady_clock::now();
+  if (what) std::fprintf(stderr, "[step50]     . %-32s %8.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+  t_last = now;
+}
+
 // ======================================================================== CSR helpers
 
 void CSRMatrix::add(int32_t r, int32_t c, double v) {
@@ -542,6 +552,7 @@ void LaplaceProblem<dim>::distribute_dofs() {
   // the active mesh, all cells of a level by index for the level DoFs.
   const int L = triangulation.n_levels();
   active_cells.clear();
+  sublap(nullptr);
   active_index_of_cell.assign((size_t)L, {});
   for (int l = 0; l < L; ++l) {
     active_index_of_cell[(size_t)l].assign(triangulation.levels[(size_t)l].size(), -1);
@@ -551,9 +562,12 @@ void LaplaceProblem<dim>::distribute_dofs() {
         active_cells.push_back({l, (int32_t)c});
       }
   }
-  dof_of_vertex.clear();
+  // (level-0 vertices index a dense array by lattice position, the others a hash table: flat_map.h)
+  const int lattice[3] = {triangulation.n0 + 1, triangulation.n0 + 1, dim == 3 ? triangulation.n0 + 1 : 1};
+  dof_of_vertex.reset(kMaxLevelShift, lattice);
   vertex_of_dof.clear();
-  dof_of_vertex.reserve(active_cells.size() * 2);
+  sublap("dofs: active cell list");
+  dof_of_vertex.reserve_sparse(active_cells.size() - (size_t)std::min<int64_t>((int64_t)active_cells.size(), (int64_t)triangulation.levels[0].size()));
   active_cell_dof_table.resize(active_cells.size() * (size_t)(1 << dim));
   size_t slot = 0;
   for (const ActiveCell &ac : active_cells) {
@@ -562,42 +576,58 @@ void LaplaceProblem<dim>::distribute_dofs() {
       const uint64_t key = triangulation.vertex_key(ac.level, cell, a);
       const auto ins = dof_of_vertex.emplace(key, (int32_t)vertex_of_dof.size());
       if (ins.second) vertex_of_dof.push_back(key);
-      active_cell_dof_table[slot++] = ins.first->second;
+      active_cell_dof_table[slot++] = *ins.first;
     }
   }
   level_dof_of_vertex.assign((size_t)L, {});
+  sublap("dofs: active numbering");
   level_vertex_of_dof.assign((size_t)L, {});
   level_cell_dof_table.assign((size_t)L, {});
   for (int l = 0; l < L; ++l) {
     auto &map = level_dof_of_vertex[(size_t)l];
     auto &vec = level_vertex_of_dof[(size_t)l];
     auto &tab = level_cell_dof_table[(size_t)l];
-    map.reserve(triangulation.levels[(size_t)l].size() * 2);
+    const int none[3] = {0, 0, 0};
+    map.reset(kMaxLevelShift, l == 0 ? lattice : none);
+    if (l > 0) map.reserve_sparse(triangulation.levels[(size_t)l].size() * 2);
     tab.resize(triangulation.levels[(size_t)l].size() * (size_t)(1 << dim));
-    size_t ls = 0;
-    for (const Cell &cell : triangulation.levels[(size_t)l])
-      for (int a = 0; a < (1 << dim); ++a) {
-        const uint64_t key = triangulation.vertex_key(l, cell, a);
-        const auto ins = map.emplace(key, (int32_t)vec.size());
-        if (ins.second) vec.push_back(key);
-        tab[ls++] = ins.first->second;
-      }
     if (l == 0 && par.level0_numbering == "lexicographic") {
       // Level 0 is the undivided lattice (subdivided_hyper_rectangle, src/step-50.cc:1526) and carries no smoother: its
       // numbering only permutes rows / columns of A_0, P_0 and the copy indices (results change in the last bits of a few
       // sums).  Vertex keys order by (z, y, x): ascending keys = lexicographic DoFs, and A_0 becomes a pure 27-point stencil
       // with strides 1, nx, nx ny -- what the device's plane-by-plane kernel (csrc/gmg_lattice.hpp) wants.  deal.II's real
       // level numbering on the reference's p4est partition is not reproducible here either way.
-      std::vector<int32_t> renum(vec.size());
-      {
-        std::vector<uint64_t> old = vec;
-        std::sort(vec.begin(), vec.end());
-        for (size_t i = 0; i < vec.size(); ++i) map[vec[i]] = (int32_t)i;
-        for (size_t i = 0; i < old.size(); ++i) renum[i] = map[old[i]];
-      }
-      for (int32_t &d : tab) d = renum[(size_t)d];
+      // DoF of a vertex = its lattice position: no table is searched, no key is sorted.
+      const int64_t nx = lattice[0], ny = lattice[1], nz = lattice[2];
+      vec.resize((size_t)(nx * ny * nz));
+#pragma omp parallel for schedule(static)
+      for (int64_t k = 0; k < nz; ++k)
+        for (int64_t j = 0; j < ny; ++j)
+          for (int64_t i = 0; i < nx; ++i) {
+            const uint64_t key = pack3((uint64_t)i << kMaxLevelShift, (uint64_t)j << kMaxLevelShift, (uint64_t)k << kMaxLevelShift);
+            vec[(size_t)(i + nx * (j + ny * k))] = key;
+          }
+      for (size_t i = 0; i < vec.size(); ++i) map.emplace(vec[i], (int32_t)i);
+      const auto &cells = triangulation.levels[0];
+#pragma omp parallel for schedule(static)
+      for (int64_t c = 0; c < (int64_t)cells.size(); ++c)
+        for (int a = 0; a < (1 << dim); ++a) {
+          const Cell &cell = cells[(size_t)c];
+          tab[(size_t)c * (size_t)(1 << dim) + (size_t)a] =
+              (int32_t)((cell.c[0] + (a & 1)) + nx * ((cell.c[1] + ((a >> 1) & 1)) + ny * (dim == 3 ? cell.c[2] + ((a >> 2) & 1) : 0)));
+        }
+      continue;
     }
+    size_t ls = 0;
+    for (const Cell &cell : triangulation.levels[(size_t)l])
+      for (int a = 0; a < (1 << dim); ++a) {
+        const uint64_t key = triangulation.vertex_key(l, cell, a);
+        const auto ins = map.emplace(key, (int32_t)vec.size());
+        if (ins.second) vec.push_back(key);
+        tab[ls++] = *ins.first;
+      }
   }
+  sublap("dofs: level numbering");
 }
 
 template <int dim>
@@ -633,14 +663,14 @@ void LaplaceProblem<dim>::make_constraints() {
           for (int q = 0; q < m; ++q)
             for (int e = 0; e < 3; ++e) s[e] += corner[ids[q]][e];
           const uint64_t key = pack3(s[0] / (uint64_t)m, s[1] / (uint64_t)m, s[2] / (uint64_t)m);
-          auto it = dof_of_vertex.find(key);
-          if (it == dof_of_vertex.end()) throw std::logic_error("hanging node without a DoF: mesh is not 2:1 balanced");
-          if (constraint_of_dof[(size_t)it->second] >= 0) return;
+          const int32_t *it = dof_of_vertex.find(key);
+          if (!it) throw std::logic_error("hanging node without a DoF: mesh is not 2:1 balanced");
+          if (constraint_of_dof[(size_t)*it] >= 0) return;
           ConstraintLine line;
           line.hanging = true;
           for (int q = 0; q < m; ++q)
             line.entries.push_back({dof_of_vertex.at(pack3(corner[ids[q]][0], corner[ids[q]][1], corner[ids[q]][2])), 1.0 / m});
-          constraint_of_dof[(size_t)it->second] = (int32_t)constraint_lines.size();
+          constraint_of_dof[(size_t)*it] = (int32_t)constraint_lines.size();
           constraint_lines.push_back(line);
         };
         if (dim == 2) {
@@ -713,8 +743,11 @@ void LaplaceProblem<dim>::setup_system(unsigned int cycle) {
   solution.assign((size_t)n, 0.0);
   system_rhs.assign((size_t)n, 0.0);
   if (cycle == 0 && par.flag_rhs_assembly && lammpsinput) rhs_assembly_optimization();
+  sublap("rhs_assembly_optimization");
   if (lammpsinput) compute_charge_densities();
+  sublap("compute_charge_densities");
   make_constraints();  // calls compute_moments() first when atoms are present (:675-679)
+  sublap("make_constraints");
 }
 
 template <int dim>
@@ -843,6 +876,7 @@ void LaplaceProblem<dim>::assemble_system() {
   const Quadrature<dim> q_laplace((int)par.degree + 1), q_rhs((int)(par.degree + par.quadrature_degree_rhs));
   const bool constant_coef = par.Problemtype != "Step16";
   // coupling lists: the cell's DoFs plus the masters of its constrained DoFs
+  sublap(nullptr);
   std::vector<int64_t> cptr(active_cells.size() + 1, 0);
   std::vector<int32_t> citems;
   citems.reserve(active_cells.size() * nv);
@@ -860,7 +894,9 @@ void LaplaceProblem<dim>::assemble_system() {
     citems.erase(std::unique(citems.begin() + (std::ptrdiff_t)begin, citems.end()), citems.end());
     cptr[ci + 1] = (int64_t)citems.size();
   }
+  sublap("assemble: coupling lists");
   system_matrix = pattern_from_cells(n, cptr, citems);
+  sublap("assemble: sparsity pattern");
   system_rhs.assign((size_t)n, 0.0);
   // "RHS on device": the cell loop records WHERE every F_i goes (DoF, slot = cell * 2^dim + i, weight) and which Dirichlet
   // terms it loses instead of forming F from densities the host does not have; gmg_rhs_assemble does the arithmetic
@@ -942,6 +978,7 @@ void LaplaceProblem<dim>::assemble_system() {
       }
     }
   }
+  sublap("assemble: matrix pass");
   for (size_t ci = 0; ci < active_cells.size(); ++ci) {
     double K[nv][nv], x0[3], h;
     int32_t dofs[nv];
@@ -985,6 +1022,7 @@ void LaplaceProblem<dim>::assemble_system() {
       }
     }
   }
+  sublap("assemble: rhs pass");
   if (rhs_dev) {
     // per-DoF gather lists in the order the loop above would have added (a stable counting sort by DoF)
     std::vector<int64_t> dof_ptr((size_t)n + 1, 0);
@@ -1017,6 +1055,7 @@ void LaplaceProblem<dim>::assemble_system() {
                          coef_table.data(), d_out), "gmg_rhs_assemble");
     chk(gmg_vec_download(gmg, system_rhs.data(), d_out, n), "gmg_vec_download");
     gmg_vec_free(gmg, d_out);
+    sublap("assemble: rhs on device");
   }
 }
 
@@ -1178,19 +1217,18 @@ void LaplaceProblem<dim>::build_transfer() {
   for (int l = 0; l + 1 < L && !transfer_on_device; ++l) build_prolongation(l);
   copy_global.assign((size_t)L, {});
   copy_level.assign((size_t)L, {});
-  for (int l = 0; l < L; ++l) {
-    std::vector<char> seen(level_vertex_of_dof[(size_t)l].size(), 0);
-    for (const ActiveCell &ac : active_cells) {
-      if (ac.level != l) continue;
-      const Cell &cell = triangulation.levels[(size_t)l][(size_t)ac.index];
-      for (int a = 0; a < nv; ++a) {
-        const uint64_t key = triangulation.vertex_key(l, cell, a);
-        const int32_t ld = level_dof_of_vertex[(size_t)l].at(key);
-        if (seen[(size_t)ld] || level_refinement_edge[(size_t)l][(size_t)ld]) continue;
-        seen[(size_t)ld] = 1;
-        copy_global[(size_t)l].push_back(dof_of_vertex.at(key));
-        copy_level[(size_t)l].push_back(ld);
-      }
+  // (active cells are listed by level, then index: one pass; DoFs from the cell tables, no vertex is looked up)
+  std::vector<std::vector<char>> seen((size_t)L);
+  for (int l = 0; l < L; ++l) seen[(size_t)l].assign(level_vertex_of_dof[(size_t)l].size(), 0);
+  for (size_t ai = 0; ai < active_cells.size(); ++ai) {
+    const ActiveCell &ac = active_cells[ai];
+    const size_t l = (size_t)ac.level;
+    for (int a = 0; a < nv; ++a) {
+      const int32_t ld = level_cell_dof_table[l][(size_t)ac.index * nv + (size_t)a];
+      if (seen[l][(size_t)ld] || level_refinement_edge[l][(size_t)ld]) continue;
+      seen[l][(size_t)ld] = 1;
+      copy_global[l].push_back(active_cell_dof_table[ai * nv + (size_t)a]);
+      copy_level[l].push_back(ld);
     }
   }
 }

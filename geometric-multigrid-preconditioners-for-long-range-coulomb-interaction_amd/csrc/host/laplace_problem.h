@@ -11,6 +11,8 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+
+#include "flat_map.h"
 #include <vector>
 
 #include "forest.h"
@@ -166,9 +168,9 @@ class LaplaceProblem {
   struct ActiveCell { int32_t level, index; };
   std::vector<ActiveCell> active_cells;
   std::vector<std::vector<int32_t>> active_index_of_cell;  // [level][cell] -> position in active_cells or -1
-  std::unordered_map<uint64_t, int32_t> dof_of_vertex;
+  VertexMap dof_of_vertex;
   std::vector<uint64_t> vertex_of_dof;
-  std::vector<std::unordered_map<uint64_t, int32_t>> level_dof_of_vertex;
+  std::vector<VertexMap> level_dof_of_vertex;
   std::vector<std::vector<uint64_t>> level_vertex_of_dof;
   std::vector<int32_t> active_cell_dof_table;                 // [active cell][vertex]: the DoFs of every active cell (cell_dofs)
   std::vector<std::vector<int32_t>> level_cell_dof_table;     // [level][cell][vertex] (level_cell_dofs)
