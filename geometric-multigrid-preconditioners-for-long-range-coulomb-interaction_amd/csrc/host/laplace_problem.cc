@@ -76,43 +76,39 @@ CSRMatrix pattern_from_cells(int64_t n, const std::vector<int64_t> &cptr, const 
   CSRMatrix A;
   A.n_rows = A.n_cols = n;
   A.rowptr.assign((size_t)n + 1, 0);
-  std::vector<std::vector<int32_t>> rows;  // filled in parallel chunks to bound memory
-  const int64_t chunk = 1 << 16;
-  std::vector<int32_t> all;
-  std::vector<int64_t> counts((size_t)n, 0);
-  // pass 1: counts
+  // rows in chunks, one thread per chunk: the sorted union of the row's cell lists goes to the chunk's buffer, the buffers
+  // are copied to their place once the row pointers are known (each row is sorted once)
+  const int64_t chunk = 1 << 13;
+  const int64_t n_chunks = (n + chunk - 1) / chunk;
+  std::vector<std::vector<int32_t>> ccols((size_t)n_chunks);
 #pragma omp parallel
   {
     std::vector<int32_t> tmp;
-#pragma omp for schedule(dynamic, 4096)
-    for (int64_t i = 0; i < n; ++i) {
-      tmp.clear();
-      for (int64_t q = dptr[(size_t)i]; q < dptr[(size_t)i + 1]; ++q) {
-        const int32_t c = dcells[(size_t)q];
-        tmp.insert(tmp.end(), citems.begin() + cptr[(size_t)c], citems.begin() + cptr[(size_t)c + 1]);
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t ch = 0; ch < n_chunks; ++ch) {
+      std::vector<int32_t> &out = ccols[(size_t)ch];
+      const int64_t i1 = std::min(n, (ch + 1) * chunk);
+      out.reserve((size_t)(i1 - ch * chunk) * 27);
+      for (int64_t i = ch * chunk; i < i1; ++i) {
+        tmp.clear();
+        for (int64_t q = dptr[(size_t)i]; q < dptr[(size_t)i + 1]; ++q) {
+          const int32_t c = dcells[(size_t)q];
+          tmp.insert(tmp.end(), citems.begin() + cptr[(size_t)c], citems.begin() + cptr[(size_t)c + 1]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        const auto e = std::unique(tmp.begin(), tmp.end());
+        A.rowptr[(size_t)i + 1] = e - tmp.begin();
+        out.insert(out.end(), tmp.begin(), e);
       }
-      std::sort(tmp.begin(), tmp.end());
-      counts[(size_t)i] = std::unique(tmp.begin(), tmp.end()) - tmp.begin();
     }
   }
-  (void)chunk;
-  for (int64_t i = 0; i < n; ++i) A.rowptr[(size_t)i + 1] = A.rowptr[(size_t)i] + counts[(size_t)i];
+  for (int64_t i = 0; i < n; ++i) A.rowptr[(size_t)i + 1] += A.rowptr[(size_t)i];
   A.col.resize((size_t)A.rowptr[(size_t)n]);
   A.val.assign((size_t)A.rowptr[(size_t)n], 0.0);
-#pragma omp parallel
-  {
-    std::vector<int32_t> tmp;
-#pragma omp for schedule(dynamic, 4096)
-    for (int64_t i = 0; i < n; ++i) {
-      tmp.clear();
-      for (int64_t q = dptr[(size_t)i]; q < dptr[(size_t)i + 1]; ++q) {
-        const int32_t c = dcells[(size_t)q];
-        tmp.insert(tmp.end(), citems.begin() + cptr[(size_t)c], citems.begin() + cptr[(size_t)c + 1]);
-      }
-      std::sort(tmp.begin(), tmp.end());
-      const auto e = std::unique(tmp.begin(), tmp.end());
-      std::copy(tmp.begin(), e, A.col.begin() + A.rowptr[(size_t)i]);
-    }
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t ch = 0; ch < n_chunks; ++ch) {
+    std::copy(ccols[(size_t)ch].begin(), ccols[(size_t)ch].end(), A.col.begin() + A.rowptr[(size_t)(ch * chunk)]);
+    std::vector<int32_t>().swap(ccols[(size_t)ch]);
   }
   return A;
 }
