@@ -11,6 +11,7 @@
 #include "gmg_sgs.hpp"
 #include "gmg_sgs_phase.hpp"
 #include "gmg_sgs_dep.hpp"
+#include "gmg_sgs_reg.hpp"
 #ifdef GMG_EXPERIMENTS
 #include "gmg_sgs_chain.hpp"  // hand-over through an LDS word instead of s_barrier: measured slower, kept as an experiment
 #endif
@@ -97,6 +98,7 @@ struct SgsPlan {
   // four-wave variant (gmg_sgs_phase.hpp): same lists, its own ranges and record stream
   bool phased = false;
   bool dep = false;  // records laid out for gmg_sgs_dep.hpp (field-major, late = updated within the last three steps)
+  bool reg = false;  // records laid out for gmg_sgs_reg.hpp (field-major, loaded straight into registers; no staging regions in LDS)
   PhRange *p_ranges = nullptr;
   uint4 *p_blk_tab = nullptr;
   std::vector<PhRange> host_pranges;
@@ -159,9 +161,10 @@ struct gmg_context {
   int coarse_chunk = 0;
   // diagnostic options (gmg_set_option / GMG_OPTIONS); the defaults are the fast paths
   int sgs_y_slots = 0;      // 0 = kSwYSlots; tests shrink it to force several LDS ranges
-  bool sgs_disable_wave = false, sgs_disable_phase = false, sgs_chain = false, sgs_dep = false, debug_upload = false, sgs_profile = false;
+  bool sgs_disable_wave = false, sgs_disable_phase = false, sgs_chain = false, sgs_dep = false, sgs_reg = false, debug_upload = false, sgs_profile = false;
   int sgs_profile_mode = 0;
   int sgs_phase_chunk = 0;         // steps per chunk of one shape (0: default)
+  int sgs_pf_lead_kb = 0;          // diagnostics: minimum lead of the prefetch wave in KB (0: default; < 0: no prefetch)
   bool sgs_phase_nocascade = false;  // every step gathers all T1 slots of its shape (comparison)
   bool sgs_phase_nosplit = false;  // the whole tail is gathered in the dependent phase (comparison / tests)
   int sgs_phase_profile = 0;  // > 0: print cycles per step of every range of the four-wave sweep
@@ -1092,13 +1095,15 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
           if (ctx->sgs_chain) hipLaunchKernelGGL(sgs_chain_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q, ctx->sgs_abort);
           else
 #endif
-          hipLaunchKernelGGL(sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
+          if (L.sgs.reg) hipLaunchKernelGGL(sgs_regs_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
+          else hipLaunchKernelGGL(sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q);
           hipError_t e = hipMemcpyAsync(h.data(), d, sizeof(unsigned long long) * 12 * nr, hipMemcpyDeviceToHost, ctx->stream);
           if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
           (void)hipFree(d);
           if (e != hipSuccess) { ctx->err = std::string("SSOR sweep profile: ") + hipGetErrorString(e); return GMG_ERR_HIP; }
           if (L.sgs.w_steps > 1000 && nbl == 1) {
-            std::fprintf(stderr, "[gmg] four-wave sweep (%s), %lld rows: per range dir steps | cycles/step | load+write-back cycles\n", ctx->sgs_chain ? "hand-over through an LDS word" : "s_barrier per phase", (long long)L.n);
+            std::fprintf(stderr, "[gmg] four-wave sweep (%s), %lld rows: per range dir steps | cycles/step | load+write-back cycles\n",
+                         L.sgs.reg ? "records global -> registers; 'reads' = issuing the loads, 'copy' = none" : ctx->sgs_chain ? "hand-over through an LDS word" : "s_barrier per phase", (long long)L.n);
             for (size_t i = 0; i < nr; ++i) {
               const PhRange &P = L.sgs.host_pranges[i];
               const double turns = std::max(1.0, P.n_steps / (double)kPhWaves);
@@ -1120,7 +1125,8 @@ int sgs_apply(gmg_context *ctx, Level &L, double *y, const double *r) {
         if (ctx->sgs_chain) hipLaunchKernelGGL(sgs_chain_kernel, dim3(nbl), dim3(kPhThreads), lds, ctx->stream, q, ctx->sgs_abort);
         else
 #endif
-        launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
+        if (L.sgs.reg) launch_timed(ctx, sgs_regs_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
+        else launch_timed(ctx, sgs_phase_kernel, dim3(nbl), dim3(kPhThreads), lds, q);
       } else {
         launch_timed(ctx, sgs_wave_kernel<false>, dim3(nbl), dim3(kSwThreads), lds, p);
       }
@@ -1488,8 +1494,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     for (int64_t i = 0; i < n && ph; ++i) ph = rp[i + 1] - rp[i] <= 2 * kPhMaxEntries;  // (cheap pre-check; the exact one is per range)
   }
   const bool dep = ph && ctx->sgs_dep;  // one dependent wave + three preparing waves (gmg_sgs_dep.hpp)
+  const bool reg = ph && !dep && ctx->sgs_reg && !ctx->sgs_chain;  // four waves, records global -> registers (gmg_sgs_reg.hpp)
+  const bool fieldmajor = dep || reg;
   const int late_steps = dep ? kDpLate : 1;
-  const int y_max = dep ? kDpYSlots : ph ? kPhYSlots : kSwYSlots;
+  const int y_max = dep ? kDpYSlots : reg ? kRgYSlots : ph ? kPhYSlots : kSwYSlots;
   int y_cap = ctx->sgs_y_slots > 0 ? ctx->sgs_y_slots : y_max;
   y_cap = std::max(64, std::min(y_cap, y_max)) & ~1;
   std::vector<PhRange> pranges;
@@ -1732,7 +1740,11 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                     const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + (double)nr * ph_stride(g, l1 + l2)) / 1024.0,
                                  p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
                     // (dep: the dependent wave's step is what counts -- ~20 cycles per T1 slot, ~8 per T2 add; the rest is the prep waves')
-                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    // (reg: no copy, no read-back; the record is 2 + 6 g + 0.75 (l1 + l2) load instructions of ~20 cycles)
+                    const double load = 60.0 + 20.0 * (2.0 + 6.0 * g + 0.75 * (l1 + l2));
+                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g
+                                        : reg ? std::max(std::max(crit, load), p2) + 0.1 * (crit + load + p2)
+                                              : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
                     if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
                   }
               if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1759,7 +1771,11 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                     const int ent = 8 * g + l1 + l2;
                     const double crit = 330.0 + 15.0 * l1 + 4.0 * l2, copy = 45.0 * (16.0 + avg_rows * ph_stride(g, l1 + l2)) / 1024.0,
                                  p1 = 150.0 + 8.0 * (2.0 + 0.75 * ent), p2 = 100.0 + 11.0 * (8 * g + l2);
-                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
+                    // (reg: no copy, no read-back; the record is 2 + 6 g + 0.75 (l1 + l2) load instructions of ~20 cycles)
+                    const double load = 60.0 + 20.0 * (2.0 + 6.0 * g + 0.75 * (l1 + l2));
+                    const double cost = dep ? 20.0 * l1 + 8.0 * l2 + 2.0 * g
+                                        : reg ? std::max(std::max(crit, load), p2) + 0.1 * (crit + load + p2)
+                                              : std::max(std::max(crit, copy), std::max(p1, p2)) + 0.1 * (crit + copy + p1 + p2);
                     if (cost < best) { best = cost; bs = Shape{g, l1, l2}; }
                   }
               if (bs.g < 0) return setup_sgs_wave(ctx, L, n, rp, col, val, n_blocks, block_row, false);
@@ -1778,11 +1794,8 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           for (size_t st = s0; st < s1; ++st) {
             const Step &S = steps[st];
             const Shape sh = shape_of[st - s0];
-            const int Gr = sh.g, L1r = sh.l1, Lr = sh.l1 + sh.l2, pstride = ph_stride(Gr, Lr);
-            const int64_t raw = 16 + (int64_t)S.nrows * pstride;
-            boff.push_back(off); bbytes.push_back(raw);
-            stream.resize((size_t)(base + off + raw), 0);
-            char *blk = stream.data() + base + off;
+            const int Gr = sh.g, L1r = sh.l1;
+            // T1 slots the step's own rows need of the chunk's shape (the dependent phase stops there)
             int t1_used = 0;
             for (int u = 0; u < S.nrows; ++u) {
               int h0 = 0, h1 = 0;
@@ -1790,6 +1803,15 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               t1_used = std::max(t1_used, h1 - h0);
             }
             t1_used = ctx->sgs_phase_nocascade ? L1r : std::min(L1r, std::max(4, (t1_used + 3) / 4 * 4));
+            // (storing the records at the step's OWN width -- head groups, T1 and T2 slots its rows really have -- was measured in
+            // round 3: the stream shrinks by 13 % only, a step's widest row is nearly as wide as its chunk's, and the branches that
+            // make P2 and CRIT stop at the step's counts cost more than the shorter copy saves: 2.52 against 2.48 ms)
+            const int gW = Gr, l1W = L1r;
+            const int Lr = sh.l1 + sh.l2, pstride = ph_stride(gW, Lr);
+            const int64_t raw = 16 + (int64_t)S.nrows * pstride;
+            boff.push_back(off); bbytes.push_back(raw);
+            stream.resize((size_t)(base + off + raw), 0);
+            char *blk = stream.data() + base + off;
             step_word.push_back((uint32_t)ph::ph_key(Gr, L1r, sh.l2) | ((uint32_t)S.nrows << 8) | ((uint32_t)t1_used << 16));
             for (int u = 0; u < S.nrows; ++u) {
               const int i = seq[(size_t)(S.first + u)];
@@ -1797,9 +1819,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               // four-wave sweep: records lane-major (one row's fields together); dep: FIELD-major -- unit k (16 bytes) of row u at
               // block + 16 + (k * nrows + u) * 16, so that a preparing wave reads a field of all rows with one coalesced load
               alignas(16) char rec_tmp[32 + 96 * 3 + 12 * kPhMaxEntries + 32];
-              char *rec = dep ? rec_tmp : blk + 16 + (size_t)u * pstride;
-              const int64_t rec_pos = dep ? base + off + 16 + (int64_t)u * 16 : base + off + 16 + (int64_t)u * pstride;
-              const int64_t pre_pos = dep ? base + off + 16 + ((int64_t)S.nrows + u) * 16 : rec_pos + 16;
+              char *rec = fieldmajor ? rec_tmp : blk + 16 + (size_t)u * pstride;
+              const int64_t rec_pos = fieldmajor ? base + off + 16 + (int64_t)u * 16 : base + off + 16 + (int64_t)u * pstride;
+              const int64_t pre_pos = fieldmajor ? base + off + 16 + ((int64_t)S.nrows + u) * 16 : rec_pos + 16;
               (dir == 0 ? rpos_f : rpos_b)[(size_t)ci] = (int32_t)(rec_pos / 8);
               if (dir == 1) prefix_pos[(size_t)i] = (int32_t)(pre_pos / 8);
               double *f = reinterpret_cast<double *>(rec);
@@ -1809,9 +1831,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
               wv[6] = my;
               wv[7] = dir == 0 ? (uint32_t)prefix_pos[(size_t)i] : 0u;
               max_aux = std::max<uint64_t>(max_aux, wv[7]); max_lds_addr = std::max<uint64_t>(max_lds_addr, my);
-              double *hv = f + 4, *tv = f + 4 + 8 * Gr;
-              uint32_t *ha = reinterpret_cast<uint32_t *>(rec + 32 + 64 * Gr + 8 * Lr), *ta = ha + 8 * Gr;
-              for (int e = 0; e < 8 * Gr; ++e) { hv[e] = 0.0; ha[e] = my; }
+              double *hv = f + 4, *tv = f + 4 + 8 * gW;
+              uint32_t *ha = reinterpret_cast<uint32_t *>(rec + 32 + 64 * gW + 8 * Lr), *ta = ha + 8 * gW;
+              for (int e = 0; e < 8 * gW; ++e) { hv[e] = 0.0; ha[e] = my; }
               for (int e = 0; e < Lr; ++e) { tv[e] = 0.0; ta[e] = my; }
               const RowCut &rc = cut[tix];
               // head [0, h0), T1 [h0, h1), T2 [h1, ne)
@@ -1825,11 +1847,11 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
                 max_lds_addr = std::max<uint64_t>(max_lds_addr, ad);
                 if (e < h0) { hv[e] = pval[(size_t)k]; ha[e] = ad; }
                 else if (e < h1) { tv[e - h0] = pval[(size_t)k]; ta[e - h0] = ad; }
-                else { tv[L1r + e - h1] = pval[(size_t)k]; ta[L1r + e - h1] = ad; }
+                else { tv[l1W + e - h1] = pval[(size_t)k]; ta[l1W + e - h1] = ad; }
                 ++e;
               }
-              if (dep)
-                for (int k = 0; k < (32 + 96 * Gr + 12 * Lr) / 16; ++k) std::memcpy(blk + 16 + ((size_t)k * S.nrows + (size_t)u) * 16, rec_tmp + 16 * k, 16);
+              if (fieldmajor)
+                for (int k = 0; k < (32 + 96 * gW + 12 * Lr) / 16; ++k) std::memcpy(blk + 16 + ((size_t)k * S.nrows + (size_t)u) * 16, rec_tmp + 16 * k, 16);
               ++tix;
             }
             off += (raw + 15) / 16 * 16;
@@ -1856,7 +1878,12 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
             const int64_t need = boff[(size_t)std::min<int64_t>(q + 12, (int64_t)boff.size() - 1)] + kPhRegion;  // by phase q - 2
             lead = std::max(lead, need - std::max<int64_t>(q - 2, 0) * step_b);
           }
+          if (ctx->sgs_pf_lead_kb > 0) lead = std::max<int64_t>(lead, (int64_t)ctx->sgs_pf_lead_kb * 1024);  // (diagnostics: a longer lead / no prefetch at all)
           P.pf_step = (uint32_t)step_b; P.pf_lead = (uint32_t)((lead + 8191) / 8192 * 8192);
+          // Measured in round 3: the four-wave sweep with LDS copies gains nothing from the touches (2.455 ms without, 2.485 with:
+          // its copies have two phases to land either way), the register variant loses 10 % without them -- so only that one, or
+          // an explicit lead, keeps the fifth wave busy.
+          if (ctx->sgs_pf_lead_kb < 0 || (ctx->sgs_pf_lead_kb == 0 && !fieldmajor)) P.pf_step = P.pf_lead = 0;
           total_steps += P.n_steps;
           dir_pranges[dir].push_back(P);
           s0 = s1;
@@ -1977,8 +2004,9 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     }
   }
   G.w_y_slots = y_slots;
-  G.w_lds_bytes = dep ? y_slots * 8 + kDpSlots * ((kDpSlotBytes + 15) / 16 * 16) + kDpFlagBytes : ph ? y_slots * 8 + kPhWaves * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
+  G.w_lds_bytes = dep ? y_slots * 8 + kDpSlots * ((kDpSlotBytes + 15) / 16 * 16) + kDpFlagBytes : reg ? y_slots * 8 + kPhJunk : ph ? y_slots * 8 + kPhWaves * kPhRegion + kPhJunk : y_slots * 8 + kSwRing + 32;
   G.dep = dep;
+  G.reg = reg;
   G.w_n_ranges = (int)(ph ? pranges.size() : ranges.size());
   G.phased = ph;
   G.host_pranges = pranges;
@@ -1989,6 +2017,7 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   HIPC(hipFuncSetAttribute((const void *)sgs_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPC(hipFuncSetAttribute((const void *)sgs_dep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPC(hipFuncSetAttribute((const void *)sgs_regs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef GMG_EXPERIMENTS
   HIPC(hipFuncSetAttribute((const void *)sgs_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
@@ -1998,6 +2027,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
   G.wave = fa.sharedSizeBytes == 0;
   if (dep) {
     HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_dep_kernel));
+    G.wave = G.wave && fa.sharedSizeBytes == 0;
+  }
+  if (reg) {
+    HIPC(hipFuncGetAttributes(&fa, (const void *)sgs_regs_kernel));
     G.wave = G.wave && fa.sharedSizeBytes == 0;
   }
 #ifdef GMG_EXPERIMENTS
@@ -3146,6 +3179,8 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "sgs_disable_wave") ctx->sgs_disable_wave = on;
   else if (k == "sgs_disable_phase") ctx->sgs_disable_phase = on;
   else if (k == "sgs_dep") ctx->sgs_dep = on;
+  else if (k == "sgs_reg") ctx->sgs_reg = on;
+  else if (k == "sgs_pf_lead_kb") ctx->sgs_pf_lead_kb = (int)value;
   else if (k == "sgs_chain") {
 #ifndef GMG_EXPERIMENTS
     if (on) return fail(ctx, GMG_ERR_UNSUPPORTED, "sgs_chain needs a -DGMG_EXPERIMENTS build (tools/build_experiments.sh)");

@@ -120,7 +120,7 @@ def _random_sparse(n, per_row, rng, reach):
     return csr(n, n, rows)
 
 
-@pytest.mark.parametrize("sweep", ["phase", "dep"])
+@pytest.mark.parametrize("sweep", ["phase", "reg", "dep"])
 @pytest.mark.parametrize("blocks", [1, 4])
 @pytest.mark.parametrize("shape", ["chain", "wide-stages", "wide-rows", "scattered"])
 def test_ssor_on_synthetic_dependency_shapes(shape, blocks, sweep):
@@ -148,6 +148,8 @@ def test_ssor_on_synthetic_dependency_shapes(shape, blocks, sweep):
     c.set_tuning(ssor_blocks=blocks)
     if sweep == "dep":  # one dependent wave fed by three preparing waves (gmg_sgs_dep.hpp)
         c.set_option("sgs_dep", 1)
+    if sweep == "reg":  # the records loaded straight into registers (gmg_sgs_reg.hpp); default: staged through LDS regions (gmg_sgs_phase.hpp)
+        c.set_option("sgs_reg", 1)
     c.load_hierarchy(hier)
     c.set_smoother(capi().SSOR, 0.5, 2)
     mg = go.OracleMG(hier, smoother=go.SSOR, omega=0.5, steps=2, ssor_blocks=blocks)

@@ -237,12 +237,12 @@ def test_single_rank_communicator_path(hier45):
     c.close()
 
 
-@pytest.mark.parametrize("blocks,variant", [(1, "phase"), (3, "phase"), (16, "phase"), (1, "phase-ranges"), (3, "phase-ranges"), (1, "phase-nosplit"), (3, "phase-nosplit"), (1, "wave"), (3, "wave"), (16, "wave"),
+@pytest.mark.parametrize("blocks,variant", [(1, "phase"), (3, "phase"), (16, "phase"), (1, "reg"), (3, "reg"), (16, "reg"), (1, "reg-ranges"), (3, "reg-ranges"), (1, "reg-nosplit"), (1, "phase-ranges"), (3, "phase-ranges"), (1, "phase-nosplit"), (3, "phase-nosplit"), (1, "wave"), (3, "wave"), (16, "wave"),
                                             (1, "dep"), (3, "dep"), (16, "dep"), (1, "dep-ranges"), (3, "dep-ranges"),
                                             (1, "ranges"), (3, "ranges"), (1, "sweep"), (3, "sweep")])
 def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
     """B-block SSOR == the reference's rank-local SGS on B ranks (block Jacobi across ranks), in the device
-    variants: the four-wave sweep (gmg_sgs_phase.hpp, the default) and the one-wave sweep (gmg_sgs.hpp), each with a
+    variants: the four-wave sweep with its records staged through LDS (gmg_sgs_phase.hpp, the default) or loaded into registers (gmg_sgs_reg.hpp), the one-dependent-wave sweep (gmg_sgs_dep.hpp) and the one-wave sweep (gmg_sgs.hpp), each with a
     block's rows in one LDS range and with the LDS budget cut to 300 doubles so that every block is swept in many
     ranges (working sets written back / reloaded in between), and the generic CSR sweep."""
     level = 4
@@ -256,7 +256,9 @@ def test_block_ssor_matches_oracle_bit_exact(hier3, blocks, variant):
         c.set_option("sgs_disable_phase", 1)
     if variant.startswith("dep"):
         c.set_option("sgs_dep", 1)
-    if variant == "phase-nosplit":
+    if variant.startswith("reg"):
+        c.set_option("sgs_reg", 1)
+    if variant in ("phase-nosplit", "reg-nosplit"):
         c.set_option("sgs_phase_nosplit", 1)
     if variant.endswith("ranges"):
         c.set_option("sgs_y_slots", 300)
