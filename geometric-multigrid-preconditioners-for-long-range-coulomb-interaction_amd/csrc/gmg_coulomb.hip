@@ -1557,10 +1557,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
       for (int32_t k = low_cnt[(size_t)i]; k < low_cnt[(size_t)i + 1]; ++k) st = std::max(st, stage[(size_t)low[(size_t)k]] + 1);
       stage[(size_t)i] = st;
       n_stages = std::max(n_stages, st + 1);
-      row_ci[(size_t)(rb + i)] = (int32_t)ci_row.size();
-      ci_row.push_back((int32_t)(rb + i));
       crow.push_back(i);
     }
+    const size_t ci_base = ci_row.size();
+    ci_row.resize(ci_base + crow.size());
     rpos_f.resize(ci_row.size(), 0);
     rpos_b.resize(ci_row.size(), 0);
     if (crow.empty()) continue;
@@ -1571,6 +1571,13 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
     {
       std::vector<int32_t> pos(sptr.begin(), sptr.end() - 1);
       for (int32_t i : crow) by_stage[(size_t)pos[(size_t)stage[(size_t)i]]++] = i;
+    }
+    // The compact copy ycur is numbered in SWEEP order (stage by stage): the rows a forward range updates are one contiguous
+    // piece of it, those of a backward range a run of stage-long pieces -- the working-set loads and write-backs at the range
+    // boundaries (a tenth of the sweep) then touch consecutive addresses instead of one cache line per row.
+    for (size_t q = 0; q < by_stage.size(); ++q) {
+      row_ci[(size_t)(rb + by_stage[q])] = (int32_t)(ci_base + q);
+      ci_row[ci_base + q] = (int32_t)(rb + by_stage[q]);
     }
     std::vector<int32_t> ws_stamp((size_t)m, -1), own_stamp((size_t)m, -1), tmp_stamp((size_t)m, -1), slot_of((size_t)m, 0);
     std::vector<int32_t> prefix_pos((size_t)m, 0);  // index (doubles) of the row's prefix field in the backward records
@@ -1612,7 +1619,10 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
       for (int t = 0; t < n_stages; ++t) {
         const int tt = dir == 0 ? t : n_stages - 1 - t;
         Step cur{(int32_t)seq.size(), 0, 0};
-        for (int32_t q = sptr[(size_t)tt]; q < sptr[(size_t)tt + 1]; ++q) {
+        // (rows of a stage are independent: the backward sweep takes them in descending order, so that the rows a backward range
+        // updates are a DEscending contiguous piece of ycur, as those of a forward range are an ascending one)
+        for (int32_t qq = sptr[(size_t)tt]; qq < sptr[(size_t)tt + 1]; ++qq) {
+          const int32_t q = dir == 0 ? qq : sptr[(size_t)tt] + sptr[(size_t)tt + 1] - 1 - qq;
           const int i = by_stage[(size_t)q];
           const int li = n_ent(i);
           const int nl = std::max(cur.len, li);
@@ -1784,6 +1794,11 @@ int setup_sgs_wave(gmg_context *ctx, Level &L, int64_t n, const int64_t *rp, con
           }
           PhRange P{};
           P.ws_off = R.ws_off; P.n_own = R.n_own; P.n_ws = R.n_ws; P.backward = dir;
+          // the rows updated here as a piece of ycur (sweep-order numbering): first index and direction, if they are one
+          P.own_ci0 = R.n_own > 0 ? ws_ci[(size_t)R.ws_off] : 0;
+          P.own_dir = dir == 0 ? 1 : -1;
+          for (int k = 0; k < R.n_own && P.own_dir; ++k)
+            if (ws_ci[(size_t)R.ws_off + (size_t)k] != P.own_ci0 + P.own_dir * k) P.own_dir = 0;
           P.n_steps = (int32_t)(s1 - s0);
           const int64_t base = ((int64_t)stream.size() + 1023) / 1024 * 1024;
           P.stream_off = base;

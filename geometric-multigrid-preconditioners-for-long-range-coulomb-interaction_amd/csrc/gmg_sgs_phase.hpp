@@ -62,7 +62,8 @@ __host__ __device__ constexpr int ph_stride(int g, int l) {
 struct PhRange {
   int64_t stream_off;
   int32_t n_steps, ws_off, n_own, n_ws, backward, G, L;  // L = L1 + L2
-  uint32_t blk_tab, L1, pad0[4];          // first entry of the range in the block table
+  uint32_t blk_tab, L1;               // first entry of the range in the block table
+  int32_t own_ci0, own_dir, pad0[2];  // own_dir = +1 / -1: slot k of the rows updated here is ycur[own_ci0 + own_dir * k] (ycur is numbered in sweep order); 0: see ws_ci
   uint32_t pf_lead, pf_step;          // prefetch wave: bytes ahead at phase 0, bytes per phase (multiples of 128)
   uint32_t stream_bytes, pad;
 };
@@ -304,7 +305,19 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     const int32_t *ws = a.ws_ci + R.ws_off;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (a.prof) t0 = __builtin_amdgcn_s_memtime();
-    for (int k0 = tid; k0 < R.n_ws; k0 += 16 * kPhThreads) {  // sixteen independent gathers in flight per thread
+    // working set -> LDS.  The rows updated here are a contiguous piece of ycur (ascending in a forward range, descending in a
+    // backward one): coalesced loads, no index list; the rows only read (~900 of ~12 000) are gathered through ws_ci.
+    const int own_dir = Rp->own_dir, own_ci0 = Rp->own_ci0;
+    const int n_direct = own_dir ? R.n_own : 0;
+    for (int k0 = tid; k0 < n_direct; k0 += 16 * kPhThreads) {
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = k0 + j * kPhThreads < n_direct ? a.ycur[own_ci0 + own_dir * (k0 + j * kPhThreads)] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (k0 + j * kPhThreads < n_direct) ylds[k0 + j * kPhThreads] = v[j];
+    }
+    for (int k0 = n_direct + tid; k0 < R.n_ws; k0 += 16 * kPhThreads) {  // sixteen independent gathers in flight per thread
       int ci[16];
       double v[16];
 #pragma unroll
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     for (int k0 = tid; k0 < R.n_own; k0 += 16 * kPhThreads) {
       int ci[16], row[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? ws[k0 + j * kPhThreads] : -1;
+      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? (own_dir ? own_ci0 + own_dir * (k0 + j * kPhThreads) : ws[k0 + j * kPhThreads]) : -1;
 #pragma unroll
       for (int j = 0; j < 16; ++j) row[j] = (R.backward && ci[j] >= 0) ? a.ci_row[ci[j]] : -1;
 #pragma unroll
