@@ -272,14 +272,39 @@ def main():
             if not all_min(ok):
                 raise SystemExit(f"communicator (rccl) could not be set up: {why}")
         transport = want
+    def run_cycles(prob):
+        out = []
+        r = None
+        for cycle in range(args.cycles):
+            r = prob.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed), marks + refines
+            out.append({"cycle": cycle, "dofs": r["dofs"], "dofs_by_level": r["dofs_by_level"],
+                        "outer_cg_iterations": r["cg_iterations"], "coarse_cg_iterations": r["coarse_iterations"],
+                        "solve_ms": round(r["solve_seconds"] * 1e3, 3), "build_matrices_ms": round(r["build_matrices_ms"], 3)})
+        return r, out
+
     t_setup = time.time()
-    rep = None
-    cycles = []
-    for cycle in range(args.cycles):
-        rep = p.run_cycle(cycle, on_device=True)  # assembles, uploads, solves once (untimed), marks + refines
-        cycles.append({"cycle": cycle, "dofs": rep["dofs"], "dofs_by_level": rep["dofs_by_level"],
-                       "outer_cg_iterations": rep["cg_iterations"], "coarse_cg_iterations": rep["coarse_iterations"],
-                       "solve_ms": round(rep["solve_seconds"] * 1e3, 3), "build_matrices_ms": round(rep["build_matrices_ms"], 3)})
+    rep, cycles, why = None, [], ""
+    try:
+        rep, cycles = run_cycles(p)
+    except RuntimeError as exc:  # (a rank whose peers' stores never arrive gives up after a bounded wait: GMG_ERR_COMM on every rank)
+        why = str(exc)
+    if not all_min(rep is not None):
+        # --transport auto on GPUs the peer transport was never run across: if its first solves fail on any rank, every
+        # rank starts over on RCCL (the line says so); anything else is an error
+        if not (launched and transport == "peer" and args.transport == "auto" and not shared):
+            raise SystemExit(f"setup cycles failed: {why or 'on another rank'}")
+        transport_note = f"auto: the peer transport failed in the first solves ({why or 'on another rank'}) -> RCCL"
+        print("[bench] " + transport_note, file=sys.stderr)
+        try:
+            p.close()
+        except Exception:
+            pass
+        p = make_problem(args.ssor_blocks)
+        ok, why = join("rccl")
+        if not all_min(ok):
+            raise SystemExit(f"communicator (rccl) could not be set up: {why}")
+        transport = "rccl"
+        rep, cycles = run_cycles(p)
     t_setup = time.time() - t_setup
     ctx = pkg.capi.Context.view(p.gmg_context())  # non-owning view of the problem's gmg_context (stats)
     comm_info = ctx.comm_info()
