@@ -389,7 +389,9 @@ def main():
         if lay >= 1 and (lay - 1) & 8:  # lattice operator: pattern-run kernel (pair loads + lane shift), with row classes or value codes
             kname = f"spmv_sellp_kernel<0, {1 if fused else 2}, {'true' if (lay - 1) & 16 else 'false'}>"
         if lay >= 1 and (lay - 1) & 32:  # lattice operator walked plane by plane (sliding window of x lines in registers)
-            kname = "spmv_lattice_kernel<2>"  # (template argument: 2 = with the d.h partials; the lattice kernel has no fused variant)
+            # (template arguments: 2 = with the d.h partials -- the lattice kernel has no fused variant --, false = every marching
+            # wave takes one column: lattices up to ~360^3; beyond, the multi-pass variant <2, true> runs)
+            kname = "spmv_lattice_kernel<2, false>" if n0 <= 360 ** 3 else "spmv_lattice_kernel<2, true>"
         # bytes the kernel actually moves: the operator in its device layout (the library reports the exact size of the
         # streams) + x read (8 N) + y written (8 N); the fused variant also reads g and writes d (16 N)
         moved = int(st.spmv0_matrix_bytes) + 16 * n0 + (16 * n0 if fused else 0)

@@ -172,6 +172,7 @@ struct gmg_context {
   int sgs_lds_bytes_override = 0;  // tests: request this much dynamic LDS for the SSOR sweep (over the limit: the launch is rejected)
   bool disable_sell = false, disable_patterns = false, disable_compression = false, disable_sellp = false, disable_rowclass = false, disable_lattice = false;
   int lattice_segments = 0;  // segments per XCD slab of the lattice kernel (0: by size)
+  int lattice_max_blocks = 0;  // cap on the marching workgroups (0: only the reduction partials cap them)
   int sell_grid = 0;        // workgroups of the SELL kernels (0 = by size)
   int sellp_rr = 0;         // round-robin slice order of the fast waves: 0 by size, 1 on, 2 off
   double sellp_cost = 4.0;  // cost of a streamed slice in pattern slices (wave balancing of spmv_sellp_kernel)
@@ -314,7 +315,12 @@ int lattice_grid(const gmg_context *ctx, DevCSR &m, size_t n_gen) {
   if (ctx->lattice_segments > 0) S = std::min(ctx->lattice_segments, slab);
   m.lat_S = S;
   m.lat_fast_blocks = 8 * ((S * m.lat_C + 3) / 4);
-  return n_gen == 0 ? 0 : (int)std::min<size_t>((size_t)std::max(64, 256 * kLatWavesPerSimd - m.lat_fast_blocks), (n_gen + 3) / 4);
+  const int n_gen_blocks = n_gen == 0 ? 0 : (int)std::min<size_t>((size_t)std::max(64, 256 * kLatWavesPerSimd - m.lat_fast_blocks), (n_gen + 3) / 4);
+  // every workgroup writes one reduction partial: beyond kMaxPartials (lattices above ~360^3) the marching waves take
+  // several (segment, column) pairs each
+  m.lat_fast_blocks = std::min(m.lat_fast_blocks, (kMaxPartials - n_gen_blocks) / 8 * 8);
+  if (ctx->lattice_max_blocks >= 8) m.lat_fast_blocks = std::min(m.lat_fast_blocks, ctx->lattice_max_blocks / 8 * 8);  // (tests: the multi-pass form on a small lattice)
+  return n_gen_blocks;
 }
 
 // the lattice interior only needs the rows whose columns are owned (< n_rows): any n_cols >= n_rows qualifies
@@ -906,7 +912,8 @@ int launch_op(gmg_context *ctx, const DevCSR &m, const SpmvArgs &a) {
         la.nx = m.lat_nx; la.nxy = m.lat_nxy; la.W = m.lat_W; la.R0 = m.lat_R0; la.R1 = m.lat_R1; la.C = m.lat_C; la.K = m.lat_K; la.S = m.lat_S;
         la.fast_blocks = m.lat_fast_blocks; la.gen_slices = m.lat_gen; la.n_gen = m.lat_n_gen;
         la.edge_mode = m.lat_only ? 1 : 0; la.n_rows = (int)m.n_rows;
-        launch_timed(ctx, spmv_lattice_kernel<CG>, dim3(m.lat_grid), dim3(kThreads), 0, la);
+        if (m.lat_S * m.lat_C > (m.lat_fast_blocks / 8) * 4) launch_timed(ctx, spmv_lattice_kernel<CG, true>, dim3(m.lat_grid), dim3(kThreads), 0, la);
+        else launch_timed(ctx, spmv_lattice_kernel<CG, false>, dim3(m.lat_grid), dim3(kThreads), 0, la);
         return m.lat_grid;
       }
     }
@@ -3185,6 +3192,7 @@ int gmg_set_option(gmg_context *ctx, const char *key, double value) {
   else if (k == "disable_rowclass") ctx->disable_rowclass = on;
   else if (k == "disable_lattice") ctx->disable_lattice = on;
   else if (k == "lattice_segments") ctx->lattice_segments = (int)value;
+  else if (k == "lattice_max_blocks") ctx->lattice_max_blocks = (int)value;
   else if (k == "sell_grid") ctx->sell_grid = (int)value;
   else if (k == "sellp_cost") ctx->sellp_cost = value;
   else if (k == "sellp_rr") ctx->sellp_rr = (int)value;

@@ -47,7 +47,9 @@ struct LatArgs {
   int C;                  // columns (units of 124 rows) per plane step = ceil(W / 124)
   int K;                  // plane steps
   int S;                  // segments per XCD slab and column
-  int fast_blocks;        // workgroups [0, fast_blocks) march; the others serve gen_slices
+  int fast_blocks;        // workgroups [0, fast_blocks) march; the others serve gen_slices.  Their waves take the S * C (segment,
+                          // column) pairs of their XCD in turn: one each on every lattice up to ~360^3, several beyond (the grid is
+                          // capped by the reduction partials)
   const int32_t *gen_slices;
   int n_gen;
   // edge_mode = 1 (operators made by gmg_set_level_matrix_lattice: no SELL streams exist): the rows outside [R0, R1) are
@@ -157,7 +159,9 @@ __global__ __launch_bounds__(kThreads) void lattice_rowclass_kernel(uint8_t *row
 }
 
 // CG = 0: y = A x.   CG = 2: the coarse CG's h = A d with the partials of d.h (returns at once when the solve is over).
-template <int CG>
+// MULTI: the marching waves take several (segment, column) pairs each (lattices above ~360^3: the grid is capped by the
+// reduction partials); a variant of its own because the loop costs the single-pass form two registers it does not have
+template <int CG, bool MULTI = false>
 __global__ __launch_bounds__(kThreads, kLatWavesPerSimd) void spmv_lattice_kernel(LatArgs A) {
   __shared__ double red[4];
   __shared__ double dict[256];
@@ -168,7 +172,10 @@ __global__ __launch_bounds__(kThreads, kLatWavesPerSimd) void spmv_lattice_kerne
   if ((int)blockIdx.x < A.fast_blocks) {
     // ---------------------------------------------------------------- marching waves
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-    const int wv = lb * 4 + wid;  // wave within its XCD: (segment, column), neighbouring columns in one workgroup
+    const int n_wv = A.S * A.C, wv_stride = (A.fast_blocks >> 3) * 4;
+    // wave within its XCD: (segment, column), neighbouring columns in one workgroup; a second pass only on lattices whose
+    // columns outnumber the grid
+    for (int wv = lb * 4 + wid, pass = 0; pass == 0 || (MULTI && wv < n_wv); wv += wv_stride, ++pass) {
     const int s = wv / A.C, c = wv - s * A.C;
     const int kx0 = (A.K * xcd) >> 3, kx1 = (A.K * (xcd + 1)) >> 3;
     int k0 = kx0 + ((kx1 - kx0) * s) / A.S, k1 = kx0 + ((kx1 - kx0) * (s + 1)) / A.S;
@@ -222,11 +229,13 @@ __global__ __launch_bounds__(kThreads, kLatWavesPerSimd) void spmv_lattice_kerne
           cls[d] = load_cls(k0 + d, voff[d]);
         }
     }
-    if constexpr (CG == 2) {
-      if (a.st->done) return;  // (read after the prologue loads were issued: one round trip for all of them)
+    if (pass == 0) {
+      if constexpr (CG == 2) {
+        if (a.st->done) return;  // (read after the prologue loads were issued: one round trip for all of them)
+      }
+      for (int i = threadIdx.x; i < A.n_classes * 27; i += kThreads) ctab[i] = A.ctab[i];
+      __syncthreads();
     }
-    for (int i = threadIdx.x; i < A.n_classes * 27; i += kThreads) ctab[i] = A.ctab[i];
-    __syncthreads();
     if (live) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
@@ -319,6 +328,7 @@ __global__ __launch_bounds__(kThreads, kLatWavesPerSimd) void spmv_lattice_kerne
       }
 #undef LAT_STEP
     }
+    }  // (passes)
   } else {
     // ---------------------------------------------------------------- the slices outside the lattice interior
     if constexpr (CG == 2) {

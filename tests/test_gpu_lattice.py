@@ -97,6 +97,38 @@ def test_lattice_kernel_bit_exact(shape, expect, segments):
     c.close(); c2.close()
 
 
+@pytest.mark.parametrize("shape", [(45, 45, 45), (64, 33, 21), (40, 31, 60)])
+@pytest.mark.parametrize("cg", [False, True])
+def test_lattice_kernel_with_several_columns_per_wave(shape, cg):
+    """Lattices above ~360^3 have more (segment, column) pairs than the grid may have workgroups (one reduction partial each):
+    the marching waves then take several pairs (spmv_lattice_kernel<CG, true>).  Forced here on small lattices by capping the
+    marching workgroups at 8 (one per XCD): same bits as the oracle, for y = A x and inside the coarse CG."""
+    rng = np.random.default_rng(11 + sum(shape))
+    m = lattice_operator(*shape, rng)
+    c = capi().Context(1)
+    c.set_option("lattice_max_blocks", 8)
+    c.set_option("lattice_segments", 2)
+    if cg:
+        c.set_tuning(cg_variant=2)
+    c.set_level_matrix(0, m)
+    assert is_lattice(int(c.stats().spmv0_layout))
+    if not cg:
+        x = rng.standard_normal(m.n_cols)
+        vx, vy = c.vector(m.n_cols, x), c.vector(m.n_rows, np.full(m.n_rows, np.nan))
+        c.spmv(0, vy, vx)
+        assert np.array_equal(vy.download(), go.spmv(m, x))
+    else:
+        b = rng.standard_normal(m.n_rows)
+        vb, vx = c.vector(m.n_rows, b), c.vector(m.n_rows)
+        it, res, rc = c.coarse_solve(vx, vb)
+        ident = np.arange(m.n_rows, dtype=np.int32)
+        mg = go.OracleMG(SimpleNamespace(system_matrix=m, level_matrices=[m], edge_matrices=[None], prolongations=[], copy_global=[ident], copy_level=[ident]))
+        x_ref, it_ref, res_ref, rc_ref = mg.coarse_solve(b)
+        assert rc == 0 and rc_ref == 0 and it == it_ref, (it, it_ref)
+        assert np.abs(vx.download() - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+    c.close()
+
+
 @pytest.mark.parametrize("shape", [(37, 23, 19), (45, 45, 45)])
 def test_coarse_cg_on_the_lattice_kernel(shape):
     """The coarse CG (src/step-50.cc:962-967: SolverCG, identity preconditioner, 1e-10 absolute) through the CG = 2 variant
