@@ -306,27 +306,39 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (a.prof) t0 = __builtin_amdgcn_s_memtime();
     // working set -> LDS.  The rows updated here are a contiguous piece of ycur (ascending in a forward range, descending in a
-    // backward one): coalesced loads, no index list; the rows only read (~900 of ~12 000) are gathered through ws_ci.
+    // backward one): coalesced loads, no index list; the rows only read (~900 .. 5 000 of ~12 000) are gathered through ws_ci.
+    // Branch-free: a lane beyond the end repeats the last element (same value, same slot), so every load of a pass is issued
+    // before the first LDS store and nothing is predicated -- with per-element guards this code was ~500 instructions and a
+    // dozen taken branches per 16 elements, 10-20 k cycles per range.  The index loads of the gathered rows are issued
+    // first: their round trip hides behind the direct part.
     const int own_dir = Rp->own_dir, own_ci0 = Rp->own_ci0;
     const int n_direct = own_dir ? R.n_own : 0;
-    for (int k0 = tid; k0 < n_direct; k0 += 16 * kPhThreads) {
-      double v[16];
+    constexpr int kU = 20;  // elements per thread and pass: two passes cover the 12 256 slots (one pass of 39 was measured slower: 35 k cycles)
+    {
+      const int n_g = R.n_ws - n_direct;  // gathered rows: slots [n_direct, n_ws)
+      int gi[kU];
+      if (n_g > 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = k0 + j * kPhThreads < n_direct ? a.ycur[own_ci0 + own_dir * (k0 + j * kPhThreads)] : 0.0;
+        for (int j = 0; j < kU; ++j) gi[j] = ws[n_direct + min(tid + j * kPhThreads, n_g - 1)];
+      }
+      for (int k0 = 0; k0 < n_direct; k0 += kU * kPhThreads) {
+        double v[kU];
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (k0 + j * kPhThreads < n_direct) ylds[k0 + j * kPhThreads] = v[j];
-    }
-    for (int k0 = n_direct + tid; k0 < R.n_ws; k0 += 16 * kPhThreads) {  // sixteen independent gathers in flight per thread
-      int ci[16];
-      double v[16];
+        for (int j = 0; j < kU; ++j) v[j] = a.ycur[own_ci0 + own_dir * min(k0 + tid + j * kPhThreads, n_direct - 1)];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_ws ? ws[k0 + j * kPhThreads] : -1;
+        for (int j = 0; j < kU; ++j) ylds[min(k0 + tid + j * kPhThreads, n_direct - 1)] = v[j];
+      }
+      for (int k0 = 0; k0 < n_g; k0 += kU * kPhThreads) {
+        double v[kU];
+        if (k0 > 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = ci[j] >= 0 ? a.ycur[ci[j]] : 0.0;
+          for (int j = 0; j < kU; ++j) gi[j] = ws[n_direct + min(k0 + tid + j * kPhThreads, n_g - 1)];
+        }
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (ci[j] >= 0) ylds[k0 + j * kPhThreads] = v[j];
+        for (int j = 0; j < kU; ++j) v[j] = a.ycur[gi[j]];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) ylds[n_direct + min(k0 + tid + j * kPhThreads, n_g - 1)] = v[j];
+      }
     }
     __syncthreads();
     if (a.prof) t1 = __builtin_amdgcn_s_memtime();
@@ -362,19 +374,33 @@ __global__ __launch_bounds__(kPhThreads) void sgs_phase_kernel(SgsPhaseArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): prefix stores, leftover copies
     __syncthreads();
     if (a.prof) t2 = __builtin_amdgcn_s_memtime();
-    for (int k0 = tid; k0 < R.n_own; k0 += 16 * kPhThreads) {
-      int ci[16], row[16];
+    // LDS -> ycur (and, after the backward sweep, y): the same lanes-repeat-the-last-element form
+    for (int k0 = 0; k0 < R.n_own; k0 += kU * kPhThreads) {
+      int kc[kU], ci[kU];
+      double v[kU];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ci[j] = k0 + j * kPhThreads < R.n_own ? (own_dir ? own_ci0 + own_dir * (k0 + j * kPhThreads) : ws[k0 + j * kPhThreads]) : -1;
+      for (int j = 0; j < kU; ++j) kc[j] = min(k0 + tid + j * kPhThreads, R.n_own - 1);
+      if (own_dir) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) row[j] = (R.backward && ci[j] >= 0) ? a.ci_row[ci[j]] : -1;
+        for (int j = 0; j < kU; ++j) ci[j] = own_ci0 + own_dir * kc[j];
+      } else {
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (ci[j] >= 0) {
-          const double v = ylds[k0 + j * kPhThreads];
-          a.ycur[ci[j]] = v;
-          if (row[j] >= 0) a.y[row[j]] = v;
-        }
+        for (int j = 0; j < kU; ++j) ci[j] = ws[kc[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < kU; ++j) v[j] = ylds[kc[j]];
+      if (R.backward) {
+        int row[kU];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) row[j] = a.ci_row[ci[j]];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) a.ycur[ci[j]] = v[j];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) a.y[row[j]] = v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < kU; ++j) a.ycur[ci[j]] = v[j];
+      }
     }
     __syncthreads();
     if (a.prof) {
